@@ -1,0 +1,26 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
+        return {k: torch.from_numpy(np.asarray(f[k])) if f[k].ndim > 0 else torch.tensor(f[k]) for k in f.files}
+
+
+@pytest.fixture
+def golden():
+    return load_golden
