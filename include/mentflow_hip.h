@@ -1,0 +1,128 @@
+/* mentflow_hip.h — C ABI of libmentflow_hip.so, the MI355X (gfx950) implementation of the MENT-Flow hot path.
+ *
+ * The reference (austin-hoover/ment-flow) is pure Python: it has no FFI of its own.  Each entry point below
+ * replaces the chain of eager PyTorch ops cited next to it (paths relative to the reference repository);
+ * INTEGRATION.md shows the ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless stated otherwise; float = IEEE binary32; row-major.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises.
+ *   - return value: 0 on success, non-zero on error (mf_last_error() gives the message, thread-local).
+ *   - no entry point allocates: scratch is passed in by the caller (sizes from the *_floats helpers).
+ */
+#ifndef MENTFLOW_HIP_H
+#define MENTFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MF_ABI_VERSION 1
+
+int mf_abi_version(void);
+const char* mf_last_error(void);
+/* 0 for the gfx950 library.  (1 only for the host-emulated kernel build under tests/emu, which is test
+ * infrastructure and is never loaded by the product package.)                                               */
+int mf_is_emulation(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Generic index gather (weight packing / gradient unpacking for the flow kernels).
+ *   dst[j] = idx[j] >= 0 ? src[idx[j]] : 0        (accumulate != 0:  dst[j] += ...)
+ * Replaces `mask * weight` in zuko.nn.MaskedLinear.forward (masked-out entries have idx = -1) and the
+ * reshape/permute of conditioner outputs (zuko MaskedAutoregressiveTransform.meta).                          */
+int mf_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Autoregressive rational-quadratic-spline flow layer  (zuko NSF layer as inverted by
+ * mentflow/generate/build.py:42-43; sampling direction of mentflow/generate/flows/zuko.py:24-29).
+ *
+ * `image` is the packed per-layer weight image (mf_flow_image_floats floats), laid out exactly as it sits in
+ * LDS: [W0 64 x S0][b0 64]{[W_l 64 x 65][b_l 64]}(hidden_layers-1)[W_out d x 64 x 65][b_out d x 64];
+ * see mentflow_amd/generate/packing.py for the row permutation of W_out.  hidden width is 64.
+ *
+ * fwd:  y[n,d] = RQS(x; MLP(x)),   logp_out[n] = (init_logp ? logN(x) : logp_in[n]) - sum_i ladj_i
+ *       (logN(x) = -1/2 |x|^2 - d/2 log 2pi: zuko DiagNormal.log_prob of the base draw, first layer only).
+ * bwd:  given gy[n,d] = dL/dy and glogp[n] = dL/dlogp, writes gx[n,d] = dL/dx (NULL for the first layer: the
+ *       base draw needs no gradient) and accumulates dL/d(image) into gimage (same layout as image; must be
+ *       zeroed by the caller before the first chunk).  `scratch` needs mf_flow_bwd_scratch_floats(n,...)
+ *       floats.                                                                                             */
+int64_t mf_flow_image_floats(int d, int hidden_layers);
+int64_t mf_flow_bwd_scratch_floats(int64_t n, int d, int hidden_layers);
+int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layers, int bins, const float* x, int64_t n,
+                          float* y, const float* logp_in, float* logp_out, int init_logp, void* stream);
+int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins, const float* x, int64_t n,
+                          const float* gy, const float* glogp, float* gx, float* gimage, float* scratch,
+                          int64_t scratch_floats, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused linear projection + 1-D Gaussian-KDE histogram over P projections.
+ * Replaces, for all P transforms at once: `x.clone() @ M.T` (mentflow/simulate/transform.py:67-68, only the
+ * consumed output row V_p of each matrix), Histogram1D.project (mentflow/diagnostics/diagnostics.py:116-122) and the
+ * residuals/exp/mean of marginal_pdf (mentflow/diagnostics/histogram.py:37-39).
+ *   S[p,k] = sum_n exp(-1/2 ((x_n . V_p - coords[k]) / sigma)^2)        (raw sums: the 1/N and the
+ *   normalisation of histogram.py:39-43 happen in mf_hist_norm_discrepancy_fwd, after any cross-GPU sum)
+ * Only the 2*radius+1 bins around each projected particle are visited (dropped kernel values are below
+ * exp(-(radius+1/2)^2 delta^2 / (2 sigma^2)), 3e-18 for the reference's sigma = delta/2 and radius 4); pass
+ * radius >= B for the dense sum.                                                                              */
+int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* V, int P, const float* coords, int B,
+                      float sigma, int radius, float* S, void* stream);
+/* gx[n,d] (+)= sum_p V_p * sum_k gS[p,k] * K_npk * (-(u_np - c_k)/sigma^2)             */
+int mf_proj_kde1d_bwd(const float* x, int64_t n, int d, const float* V, int P, const float* coords, int B,
+                      float sigma, int radius, const float* gS, float* gx, int accumulate, void* stream);
+
+/* 2-D variant: two projection vectors per transform (rows `axis[0]`, `axis[1]` of the matrix); replaces
+ * Histogram2D.project + marginal_pdf x2 + joint_pdf's Kx^T Ky (histogram.py:47-74,89-101).
+ *   S[p,a,b] = sum_n Kx_na Ky_nb   (no 1/N, as the reference)                                                */
+int mf_proj_kde2d_fwd(const float* x, int64_t n, int d, const float* V0, const float* V1, int P,
+                      const float* coords_x, int Bx, float sigma_x, int radius_x, const float* coords_y, int By,
+                      float sigma_y, int radius_y, float* S, void* stream);
+int mf_proj_kde2d_bwd(const float* x, int64_t n, int d, const float* V0, const float* V1, int P,
+                      const float* coords_x, int Bx, float sigma_x, int radius_x, const float* coords_y, int By,
+                      float sigma_y, int radius_y, const float* gS, float* gx, int accumulate, void* stream);
+
+/* Hard-binned projection histograms (measurement generation / eval): counts[p,k] of u = x.V_p in uniform bins
+ * [lo, lo + B*delta], out-of-range ignored, last bin right-inclusive: torch.histogram semantics
+ * (mentflow/diagnostics/diagnostics.py:128-131); density/renormalisation is done by the caller.                */
+int mf_proj_hist1d_counts(const float* x, int64_t n, int d, const float* V, int P, const float* edges, int B,
+                          int32_t* counts, void* stream);
+int mf_proj_hist2d_counts(const float* x, int64_t n, int d, const float* V0, const float* V1, int P,
+                          const float* edges_x, int Bx, const float* edges_y, int By, int32_t* counts,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Histogram normalisation + discrepancy for P projections (tiny: P*bins elements; one workgroup per projection).
+ *   normalize != 0:  prob = S * pre_scale   (1-D: pre_scale = 1/N_total, histogram.py:39;  2-D: 1, histogram.py:69)
+ *                    ghat = prob / (sum(prob) * cell + eps)                        (histogram.py:40-43,70-73)
+ *   normalize == 0:  ghat = S  (S already is a prediction; the standalone discrepancy functions)
+ *   meas != NULL:    kind 0 (kld): D_p = sum[xlogy(m,m) - m*log(ghat+pad)] / batch_div     (mentflow/loss.py:15-17;
+ *                                  batch_div = pred.shape[0] = B for 1-D, Bx for 2-D predictions)
+ *                    kind 1 (mae): D_p = sum|ghat-m| / batch_div  (loss.py:7-8, batch_div = number of bins)
+ *                    kind 2 (mse): D_p = sum(ghat-m)^2 / batch_div (loss.py:11-12)
+ *   ghat may be NULL (not wanted), meas/D may be NULL (normalisation only).
+ * bwd: gS[p,k] = dL/dS from gD[p] = dL/dD_p (may be NULL) and/or gghat[p,k] = dL/dghat (may be NULL);
+ *      closed form of SURVEY.md Appendix B.                                                                  */
+int mf_hist_norm_discrepancy_fwd(const float* S, int P, int bins, int normalize, float pre_scale, float cell,
+                                 float eps, const float* meas, int kind, float pad, float batch_div, float* ghat,
+                                 float* D, void* stream);
+int mf_hist_norm_discrepancy_bwd(const float* S, int P, int bins, int normalize, float pre_scale, float cell,
+                                 float eps, const float* meas, int kind, float pad, float batch_div, const float* gD,
+                                 const float* gghat, float* gS, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Monte-Carlo entropy sums  (mentflow/entropy.py:58-62 + mentflow/prior.py:25-26):
+ *   out[0] = sum_n logp[n],  out[1] = sum_n |x_n|^2      (means / prior constants applied by the caller after
+ *   any cross-GPU sum; scratch2 = two doubles of device scratch).
+ *   mf_scale_rows: gx[n,:] (+)= coef[0] * cscale * x[n,:]  — the adjoint of the |x|^2 term; coef is a DEVICE
+ *   scalar (the upstream gradient) so that no host synchronisation is needed.                                 */
+int mf_mc_entropy_sums(const float* x, const float* logp, int64_t n, int d, float* out2, double* scratch2,
+                       void* stream);
+int mf_scale_rows(const float* x, int64_t n, int d, const float* coef, float cscale, float* gx, int accumulate,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MENTFLOW_HIP_H */

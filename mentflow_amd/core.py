@@ -1,0 +1,203 @@
+"""MENT-Flow model — mirrors mentflow/core.py:18-161 (same constructor kwargs, attributes and return values)."""
+from __future__ import annotations
+
+from typing import Callable, Iterator, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import dist as mfdist
+from . import ops
+from .diagnostics import Histogram, Histogram1D, Histogram2D
+from .entropy import EmptyEntropyEstimator, MonteCarloEntropyEstimator
+from .generate import GenerativeModel
+from .loss import kl_divergence
+from .simulate import forward, group_measurements
+from .utils import unravel
+
+
+class MENTFlow(nn.Module):
+    """Generative maximum-entropy tomography solver (core.py:18-61)."""
+
+    def __init__(self, transforms: List[nn.Module], diagnostics: List[List[nn.Module]],
+                 measurements: List[List[torch.Tensor]], generator: GenerativeModel, prior, entropy_estimator: Callable,
+                 discrepancy_function: Callable = kl_divergence, penalty_parameter: float = 10.0) -> None:
+        super().__init__()
+        self.transforms = transforms
+        self.diagnostics = self.set_diagnostics(diagnostics)
+        self.measurements = self.set_measurements(measurements)
+        self.generator = generator
+        self.entropy_estimator = entropy_estimator
+        self.discrepancy_function = discrepancy_function
+        self.penalty_parameter = penalty_parameter
+        self._plan = None
+        self._plan_key = None
+
+    def set_diagnostics(self, diagnostics):
+        self.diagnostics = diagnostics
+        if self.diagnostics is None:
+            self.diagnostics = [[]]
+        return self.diagnostics
+
+    def set_measurements(self, measurements):
+        self.measurements = measurements
+        if self.measurements is None:
+            self.measurements = [[]]
+        return self.measurements
+
+    # ------------------------------------------------------------------ reference API (core.py:75-93)
+    def sample(self, size: int) -> torch.Tensor:
+        return self.generator.sample(int(size))
+
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        return self.generator.log_prob(x)
+
+    def sample_and_log_prob(self, size: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.generator.sample_and_log_prob(size)
+
+    def sample_and_entropy(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        x, log_prob = self.sample_and_log_prob(n)
+        H = self.entropy_estimator(x, log_prob)
+        return (x, H)
+
+    def discrepancy_vector(self, predictions: List[List[torch.Tensor]]) -> List[torch.Tensor]:
+        return [self.discrepancy_function(pred, meas)
+                for pred, meas in zip(unravel(predictions), unravel(self.measurements))]
+
+    # ------------------------------------------------------------------ fused step
+    def _fused_plan(self):
+        """Static launch plan of the fused loss: one entry per distinct diagnostic object (the reference shares ONE
+        Histogram object across all transforms, experiments/setup.py:43-44)."""
+        kind = getattr(self.discrepancy_function, "kind", None)
+        if kind is None or not isinstance(self.entropy_estimator, (MonteCarloEntropyEstimator, EmptyEntropyEstimator)):
+            return None
+        key = (tuple(id(t) for t in self.transforms), tuple(id(d) for d in unravel(self.diagnostics)),
+               tuple(id(m) for m in unravel(self.measurements)),
+               tuple((d.kde, d.noise and d.noise_scale > 0.0) for d in unravel(self.diagnostics)))
+        if self._plan is not None and self._plan_key == key:
+            return self._plan
+        groups = group_measurements(self.transforms, self.diagnostics)
+        order = {}
+        pos = 0
+        for i in range(len(self.transforms)):
+            for j in range(len(self.diagnostics[i])):
+                order[(i, j)] = pos
+                pos += 1
+        plan = []
+        for diagnostic, slots, rows in groups.values():
+            if not diagnostic.kde or (diagnostic.noise and diagnostic.noise_scale > 0.0):
+                return None
+            stacked = [torch.stack([r[k] for r in rows]).to(torch.float32).contiguous() for k in range(len(rows[0]))]
+            meas = torch.stack([self.measurements[i][j] for (i, j) in slots]).to(torch.float32)
+            meas = meas.reshape(len(slots), -1).contiguous()
+            plan.append((diagnostic, stacked, meas, [order[s] for s in slots]))
+        self._plan, self._plan_key = (plan, pos, kind), key
+        return self._plan
+
+    def loss(self, batch_size: int) -> Tuple[torch.Tensor, torch.Tensor, List[torch.Tensor]]:
+        """L = H + mu * mean_p D_p from a fresh batch (core.py:95-117).  ``batch_size`` is the GLOBAL number of
+        particles; under torch.distributed every rank samples its share and two all-reduces make (L, H, D) and the
+        parameter gradients identical to the single-GPU values (mentflow_amd/dist.py)."""
+        plan = self._fused_plan()
+        if plan is None:
+            if mfdist.is_active():
+                raise NotImplementedError("data-parallel loss needs the fused path (KDE histograms, kld/mae/mse)")
+            x, H = self.sample_and_entropy(batch_size)
+            predictions = forward(x, self.transforms, self.diagnostics)
+            D = self.discrepancy_vector(predictions)
+            L = H + self.penalty_parameter * (sum(D) / len(D))
+            return (L, H, D)
+
+        groups, n_meas, kind = plan
+        n_total = int(batch_size)
+        n_local = mfdist.local_batch(n_total)
+        if mfdist.is_active() and getattr(self.generator, "grad_reduce", None) is None:
+            self.generator.grad_reduce = mfdist.reduce_gradients_
+        x, log_prob = self.generator.sample_and_log_prob(n_local)
+
+        use_entropy = isinstance(self.entropy_estimator, MonteCarloEntropyEstimator)
+        pieces = []
+        for diagnostic, rows, meas, _ in groups:
+            if isinstance(diagnostic, Histogram1D):
+                S = ops.ProjKde1dFn.apply(x, rows[0], diagnostic.coords, float(diagnostic.bandwidth),
+                                          ops.kde_radius(diagnostic.bandwidth_bins))
+            else:
+                S = ops.ProjKde2dFn.apply(x, rows[0], rows[1], diagnostic.coords_x, diagnostic.coords_y,
+                                          float(diagnostic.bandwidth_x), float(diagnostic.bandwidth_y),
+                                          ops.kde_radius(diagnostic.bandwidth_bins[0]),
+                                          ops.kde_radius(diagnostic.bandwidth_bins[1]))
+            pieces.append(S.reshape(-1))
+        if use_entropy:
+            pieces.append(ops.EntropySumsFn.apply(x, log_prob))
+        if mfdist.is_active():
+            flat = mfdist.all_reduce_sum(torch.cat(pieces))
+            sizes = [p.numel() for p in pieces]
+            pieces = list(torch.split(flat, sizes))
+
+        D_slots: List[Optional[torch.Tensor]] = [None] * n_meas
+        D_sum = None
+        for (diagnostic, rows, meas, positions), S in zip(groups, pieces):
+            P = meas.shape[0]
+            if isinstance(diagnostic, Histogram1D):
+                pre_scale, cell, div = 1.0 / n_total, float(diagnostic.resolution), float(meas.shape[1])
+            else:
+                pre_scale, cell = 1.0, float(diagnostic.resolution_x * diagnostic.resolution_y)
+                div = float(diagnostic.coords_x.numel())
+            if kind != "kld":
+                div = float(meas.shape[1])
+            _, Dg = ops.HistNormDiscFn.apply(S.reshape(P, -1), meas, True, pre_scale, cell, 1.0e-10,
+                                             ops.DISCREPANCY_KINDS[kind], 1.0e-12 if kind == "kld" else 0.0, div)
+            for pos, dval in zip(positions, Dg.unbind(0)):
+                D_slots[pos] = dval
+            D_sum = Dg.sum() if D_sum is None else D_sum + Dg.sum()
+        if use_entropy:
+            H = self.entropy_estimator.from_sums(pieces[-1], n_total)
+        else:
+            H = torch.zeros((), dtype=torch.float32, device=x.device)
+        L = H + self.penalty_parameter * (D_sum / n_meas)
+        return (L, H, D_slots)
+
+    # ------------------------------------------------------------------ parameters / checkpoints (core.py:119-159)
+    def parameters(self) -> Iterator[nn.Parameter]:
+        return self.generator.parameters()
+
+    def save(self, path) -> None:
+        state = {
+            "generator": self.generator.state_dict(),
+            "entropy_estimator": self.entropy_estimator,
+            "transforms": self.transforms,
+            "diagnostics": self.diagnostics,
+            "measurements": self.measurements,
+        }
+        torch.save(state, path)
+
+    def load(self, path, device=None):
+        state = torch.load(path, map_location=device, weights_only=False)
+        try:
+            self.generator.load_state_dict(state["generator"])
+        except RuntimeError:
+            raise RuntimeError("Error loading generative model. Architecture mismatch?")
+        self.entropy_estimator = state["entropy_estimator"]
+        self.transforms = state["transforms"]
+        self.diagnostics = state["diagnostics"]
+        self.measurements = state["measurements"]
+        self.to(device)
+
+    def to(self, device):
+        if self.transforms is not None:
+            for transform in self.transforms:
+                transform.to(device)
+        if self.diagnostics is not None:
+            for index in range(len(self.diagnostics)):
+                for diagnostic in self.diagnostics[index]:
+                    diagnostic.to(device)
+        if self.measurements is not None:
+            for index in range(len(self.measurements)):
+                self.measurements[index] = [m.to(device) for m in self.measurements[index]]
+        if self.generator is not None:
+            self.generator = self.generator.to(device)
+        prior = getattr(self.entropy_estimator, "prior", None)
+        if prior is not None and hasattr(prior, "to"):
+            prior.to(device)
+        self._plan = None
+        return self

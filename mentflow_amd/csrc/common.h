@@ -1,0 +1,39 @@
+// Shared helpers for the gfx950 kernels of libmentflow_hip.so.
+#pragma once
+#ifndef MF_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mentflow_hip.h"
+
+namespace mf {
+
+// error text of the last failing entry point on this host thread
+extern thread_local char g_err[512];
+int fail(const char* fmt, ...);
+int check_launch(const char* what);
+
+constexpr int WAVE = 64;
+constexpr int NUM_CU = 256;   // MI355X: 8 XCDs x 32 CUs
+
+#ifdef MF_EMU
+#define MF_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    emu::launch(dim3(grid), dim3(block), (smem), [&]() { kernel(__VA_ARGS__); })
+#define MF_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(((uintptr_t)emu::g_block->dyn_smem + 63) & ~(uintptr_t)63)
+#define MF_ALLOW_DYN_SMEM(kernel, bytes) ((void)0)
+#else
+#define MF_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#define MF_DYN_SMEM(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_[]; \
+    type* name = reinterpret_cast<type*>(name##_raw_)
+// LDS beyond 64 KiB per workgroup has to be requested explicitly (gfx950 allows 160 KiB)
+#define MF_ALLOW_DYN_SMEM(kernel, bytes) \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+#endif
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+}  // namespace mf

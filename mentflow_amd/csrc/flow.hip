@@ -1,0 +1,633 @@
+// Autoregressive flow layer kernels for gfx950: masked-MLP conditioner on fp32 MFMA fused with the
+// rational-quadratic-spline (NSF) or affine (MAF) univariate transform and its log-det.
+//
+// What this replaces (reference = austin-hoover/ment-flow, arithmetic in zuko 1.3.1):
+//   WrappedZukoFlow.sample_and_log_prob / forward        mentflow/generate/flows/zuko.py:24-29
+//   build_flow (NSF / MAF, inverted)                     mentflow/generate/build.py:13-46
+//   zuko MaskedMLP (4x F.linear(x, mask*W, b) + ReLU), MonotonicRQSTransform / MonotonicAffineTransform
+//   call_and_ladj, DependentTransform ladj sum, DiagNormal.log_prob — and their autograd backward.
+//
+// Layout of the computation (one launch per flow layer, forward and backward):
+//   * the layer's masked weights ("image", <= 154 KiB) are staged once per workgroup into LDS in natural
+//     [out][in] order with an odd row stride (65 / d|1): both the forward fragments A[out][k] and the
+//     transposed fragments A[in][k=out] needed by the backward are then conflict-free ds_read_b32 streams.
+//   * a wave owns a tile of 32 particles: particle = MFMA column (lane & 31), features = MFMA rows
+//     (accumulator registers).  v_mfma_f32_32x32x2_f32 with the WEIGHTS as the A operand and the activations as
+//     the B operand: the accumulator of one layer (lane half hh holds rows (r&3)+8(r>>2)+4hh) is fed back as the
+//     B operand of the next layer with the k-pairing (row of half 0, row of half 1) — activations never leave
+//     registers, no LDS round trip, no transposes.
+//   * the 3K-1 spline parameters of one feature land in the two lanes (col, col+32) of the particle: widths (+ the
+//     first half of the derivatives) in half 0, heights (+ the rest) in half 1 — the output rows of the last
+//     linear layer are permuted for that when the image is packed (mentflow_amd/generate/packing.py).  Both
+//     softmaxes run in the same instructions; five ds_bpermute exchanges finish a spline evaluation.
+//   * backward recomputes the forward from the layer input (nothing but x[N,d] per layer is saved), produces
+//     dL/dx in registers the same way (transposed fragments), and writes the per-particle pre-activation gradients
+//     and activations as 256-byte rows to an HBM scratch, laid out so that the parameter-gradient contraction over
+//     particles (outer_accum kernel, particles = MFMA k) reads both operands as coalesced fragments.
+#include "common.h"
+
+namespace mf {
+
+constexpr int HID = 64;              // hidden width of the conditioner (reference default, config/gen/flow.yaml:3)
+constexpr int WS = HID + 1;          // LDS row stride of the 64-wide weight matrices (odd: conflict-free)
+constexpr int FLOW_BLOCK = 512;      // 8 waves, one workgroup per CU (the image fills most of the 160 KiB LDS)
+constexpr int FLOW_WAVES = FLOW_BLOCK / WAVE;
+constexpr int FLOW_DMAX = 7;         // d*64*65 + trunk must fit LDS
+constexpr float RQS_BOUND = 5.0f;
+constexpr float LOG_SLOPE_INV = 1.0f / 6.907755278982137f;   // 1/|log(1e-3)|
+
+// row (within a 32-row MFMA tile) held by accumulator register r of lane half hh
+__device__ __forceinline__ constexpr int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+struct ImageLayout {
+    int S0, offW0, offB0, offWh, offW3, offB3, total;
+};
+__host__ __device__ inline ImageLayout image_layout(int d, int L, int nblk) {
+    ImageLayout g;
+    g.S0 = d | 1;
+    g.offW0 = 0;
+    g.offB0 = HID * g.S0;
+    g.offWh = g.offB0 + HID;
+    g.offW3 = g.offWh + (L - 1) * (HID * WS + HID);
+    g.offB3 = g.offW3 + nblk * HID * WS;
+    g.total = g.offB3 + nblk * HID;
+    return g;
+}
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16_t mfma(float a, float b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void stage_image(float* lds, const float* __restrict__ image, int total) {
+    for (int i = threadIdx.x * 4; i < total; i += FLOW_BLOCK * 4)
+        *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(image + i);
+    __syncthreads();
+}
+
+// bias[32*rt + row] broadcast into the accumulator layout
+__device__ __forceinline__ f32x16_t bias_tile(const float* b, int rt, int hh) {
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b[32 * rt + rowmap(r, hh)];
+    return acc;
+}
+
+// out[2] = W[64 x 64] * in[2]  (+ bias), weights natural [out][in] with stride WS
+__device__ __forceinline__ void linear64(const float* W, const float* b, const f32x16_t (&in)[2], f32x16_t (&out)[2],
+                                         int col, int hh) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x16_t acc = bias_tile(b, rt, hh);
+        const float* wrow = W + (32 * rt + col) * WS + 4 * hh;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
+            acc = mfma(wrow[kk], in[s >> 4][s & 15], acc);
+        }
+        out[rt] = acc;
+    }
+}
+
+// out[2] += W^T * in[2]   (out rows = input units of W, contraction over W's output units)
+__device__ __forceinline__ void linear64_t(const float* W, const f32x16_t (&in)[2], f32x16_t (&out)[2], int col, int hh) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x16_t acc = out[rt];
+        const float* wcol = W + 4 * hh * WS + 32 * rt + col;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
+            acc = mfma(wcol[kk * WS], in[s >> 4][s & 15], acc);
+        }
+        out[rt] = acc;
+    }
+}
+
+__device__ __forceinline__ void relu2(f32x16_t (&h)[2]) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[rt][r] = fmaxf(h[rt][r], 0.0f);
+}
+
+// input layer: h = relu(W0[64 x d] * x + b0);  xb[s] = x[2s + hh] (0 beyond d)
+__device__ __forceinline__ void input_layer(const float* W0, const float* b0, int S0, int d, const float (&xb)[4],
+                                            f32x16_t (&h)[2], int col, int hh) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x16_t acc = bias_tile(b0, rt, hh);
+        const float* wrow = W0 + (32 * rt + col) * S0 + hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (2 * s < d) acc = mfma(wrow[2 * s], xb[s], acc);
+        h[rt] = acc;
+    }
+    relu2(h);
+}
+
+__device__ __forceinline__ float soft_clip(float v, float a) { return v * fast_rcp(fmaf(fabsf(v), a, 1.0f)); }
+__device__ __forceinline__ float soft_clip_grad(float v, float a) {
+    const float ia = fast_rcp(fmaf(fabsf(v), a, 1.0f));
+    return ia * ia;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Rational-quadratic spline of one feature, evaluated cooperatively by the two lanes (col, col+32) of a particle.
+// v[32]: this lane's slots of the conditioner output (half 0: K widths, then derivatives 0..KD0-1;
+//        half 1: K heights, then derivatives KD0..K-2).  zuko MonotonicRQSTransform.
+// BWD: also returns g[32] = dL/dv (same slot layout) and gx = dL/dx (direct path) for upstream gy = dL/dy,
+//      gl = dL/dladj.
+template <int K, bool BWD>
+__device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh, float& y_out, float& ladj_out,
+                                          float gy, float gl, float (&g)[32], float& gx_out) {
+    constexpr int KD0 = K / 2;            // derivatives owned by half 0 (interior knots 1..KD0)
+    constexpr int KD1 = K - 1 - KD0;      // derivatives owned by half 1
+    constexpr float A2 = 2.0f * LOG_SLOPE_INV;
+    constexpr float A1 = LOG_SLOPE_INV;
+    static_assert(K + KD0 <= 32, "spline does not fit the 32 slots of a lane half");
+
+    // soft clip + softmax over this half's K logits
+    float p[K];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        p[m] = soft_clip(v[m], A2);
+        mx = fmaxf(mx, p[m]);
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        p[m] = expf(p[m] - mx);
+        sum += p[m];
+    }
+    const float inv = 1.0f / sum;
+    // cumulative probabilities (torch.cumsum on CPU accumulates in double) and the bin search on the widths
+    float cj[K + 1];
+    cj[0] = 0.0f;
+    double c = 0.0;
+    int cnt = (-RQS_BOUND < x) ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        p[j] *= inv;
+        c += (double)p[j];
+        cj[j + 1] = (float)c;
+        cnt += (RQS_BOUND * (2.0f * cj[j + 1] - 1.0f) < x) ? 1 : 0;
+    }
+    cnt = __shfl_xor(cnt, 32) * hh + cnt * (1 - hh);          // the count of half 0 (widths) for both lanes
+    const int k = cnt - 1;
+    const bool inrange = (cnt >= 1) && (cnt <= K);
+    float ck = 0.0f, ck1 = 1.0f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const bool sel = (k == j);
+        ck = sel ? cj[j] : ck;
+        ck1 = sel ? cj[j + 1] : ck1;
+    }
+    const float kn0 = RQS_BOUND * (2.0f * ck - 1.0f);
+    const float kn1 = RQS_BOUND * (2.0f * ck1 - 1.0f);
+    const float on0 = __shfl_xor(kn0, 32);
+    const float on1 = __shfl_xor(kn1, 32);
+    const float x0 = hh ? on0 : kn0, x1 = hh ? on1 : kn1;
+    const float y0 = hh ? kn0 : on0, y1 = hh ? kn1 : on1;
+    // raw derivative logits at knots k and k+1 (0 at the boundary knots: exp(0) = 1)
+    const int base = hh ? KD0 : 0;
+    const int nown = hh ? KD1 : KD0;
+    float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KD0; ++j) {
+        const bool own = j < nown;
+        r0 = (own && (k - 1 == base + j)) ? v[K + j] : r0;
+        r1 = (own && (k == base + j)) ? v[K + j] : r1;
+    }
+    r0 += __shfl_xor(r0, 32);
+    r1 += __shfl_xor(r1, 32);
+    const float d0 = expf(soft_clip(r0, A1));
+    const float d1 = expf(soft_clip(r1, A1));
+
+    const float w = x1 - x0;
+    const float iw = fast_rcp(w);
+    const float hgt = y1 - y0;
+    const float s = hgt * iw;
+    const float z = (x - x0) * iw;
+    const float omz = 1.0f - z;
+    const float z1 = z * omz;
+    const float beta = d0 + d1 - 2.0f * s;
+    const float num = s * z * z + d0 * z1;
+    const float den = fmaf(beta, z1, s);
+    const float iden = fast_rcp(den);
+    const float R = num * iden;
+    const float Q = 2.0f * s * z1 + d0 * omz * omz + d1 * z * z;
+    const float jac = s * s * Q * iden * iden;
+    y_out = inrange ? fmaf(hgt, R, y0) : x;
+    ladj_out = inrange ? logf(jac) : 0.0f;
+
+    if (BWD) {
+        const float tz = 1.0f - 2.0f * z;
+        const float num_z = 2.0f * s * z + d0 * tz;
+        const float den_z = beta * tz;
+        const float R_z = (num_z - R * den_z) * iden;
+        const float den_s = 1.0f - 2.0f * z1;
+        const float R_s = (z * z - R * den_s) * iden;
+        const float R_d0 = z1 * (1.0f - R) * iden;
+        const float R_d1 = -R * z1 * iden;
+        const float iQ = fast_rcp(Q);
+        const float Q_z = 2.0f * s * tz - 2.0f * d0 * omz + 2.0f * d1 * z;
+        const float l_z = Q_z * iQ - 2.0f * den_z * iden;
+        const float l_s = 2.0f * fast_rcp(s) + 2.0f * z1 * iQ - 2.0f * den_s * iden;
+        const float l_d0 = omz * omz * iQ - 2.0f * z1 * iden;
+        const float l_d1 = z * z * iQ - 2.0f * z1 * iden;
+        const float gyh = gy * hgt;
+        const float Gz = gyh * R_z + gl * l_z;
+        const float Gs = gyh * R_s + gl * l_s;
+        const float Gd0 = gyh * R_d0 + gl * l_d0;
+        const float Gd1 = gyh * R_d1 + gl * l_d1;
+        const float Gh = gy * R;
+        gx_out = inrange ? Gz * iw : gy;
+        const float gx0 = (Gz * (z - 1.0f) + Gs * s) * iw;
+        const float gx1 = -(Gz * z + Gs * s) * iw;
+        const float gy0 = gy - Gh - Gs * iw;
+        const float gy1 = Gh + Gs * iw;
+        // knots -> cumulative probabilities -> softmax -> soft clip (this half's own K logits)
+        const float gcA = inrange ? 2.0f * RQS_BOUND * (hh ? gy0 : gx0) : 0.0f;
+        const float gcB = inrange ? 2.0f * RQS_BOUND * (hh ? gy1 : gx1) : 0.0f;
+        const float dot = gcA * ck + gcB * ck1;
+#pragma unroll
+        for (int m = 0; m < K; ++m) {
+            const float gp = ((m < k) ? gcA : 0.0f) + ((m <= k) ? gcB : 0.0f);
+            g[m] = p[m] * (gp - dot) * soft_clip_grad(v[m], A2);
+        }
+        const float gr0 = inrange ? Gd0 * d0 * soft_clip_grad(r0, A1) : 0.0f;
+        const float gr1 = inrange ? Gd1 * d1 * soft_clip_grad(r1, A1) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32 - K; ++j) {
+            const bool own = j < nown;
+            float t = 0.0f;
+            t = (own && (k - 1 == base + j)) ? gr0 : t;
+            t = (own && (k == base + j)) ? t + gr1 : t;
+            g[K + j] = t;
+        }
+    }
+}
+
+// A[in rows of tile] fragment of one output block (64 padded rows) of the last linear layer
+__device__ __forceinline__ void block_linear(const float* W, const float* b, const f32x16_t (&in)[2], float (&v)[32],
+                                             int col, int hh) {
+    f32x16_t phi[2];
+    linear64(W, b, in, phi, col, hh);
+#pragma unroll
+    for (int m = 0; m < 32; ++m) v[m] = phi[m >> 4][m & 15];
+}
+
+__device__ __forceinline__ float base_log_prob(const float* xp, int d) {
+    float q = 0.0f;
+    for (int j = 0; j < d; ++j) q = fmaf(xp[j], xp[j], q);
+    return -0.5f * q - 0.9189385332046727f * (float)d;
+}
+
+// =========================================================================================== forward, RQS
+template <int K, int L>
+__global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_fwd_kernel(const float* __restrict__ image, int d,
+                                                                   const float* __restrict__ x, int64_t n,
+                                                                   float* __restrict__ y,
+                                                                   const float* __restrict__ logp_in,
+                                                                   float* __restrict__ logp_out, int init_logp) {
+    MF_DYN_SMEM(float, lds);
+    const ImageLayout g = image_layout(d, L, d);
+    stage_image(lds, image, g.total);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+    const int64_t ntiles = (n + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * FLOW_WAVES + wid; tile < ntiles; tile += (int64_t)gridDim.x * FLOW_WAVES) {
+        const int64_t p = tile * 32 + col;
+        const bool valid = p < n;
+        const float* xp = x + (valid ? p : n - 1) * d;
+        float xb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xb[s] = (2 * s + hh < d) ? xp[2 * s + hh] : 0.0f;
+        f32x16_t h[2];
+        input_layer(lds + g.offW0, lds + g.offB0, g.S0, d, xb, h, col, hh);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            f32x16_t t[2];
+            const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
+            linear64(W, W + HID * WS, h, t, col, hh);
+            relu2(t);
+            h[0] = t[0];
+            h[1] = t[1];
+        }
+        float ladj = 0.0f;
+        for (int i = 0; i < d; ++i) {
+            float v[32], gdummy[32];
+            block_linear(lds + g.offW3 + i * HID * WS, lds + g.offB3 + i * HID, h, v, col, hh);
+            float yi, li, gxd;
+            rqs_apply<K, false>(v, xp[i], hh, yi, li, 0.0f, 0.0f, gdummy, gxd);
+            ladj += li;
+            if (valid && hh == 0) y[p * d + i] = yi;
+        }
+        if (valid && hh == 0) {
+            const float lp0 = init_logp ? base_log_prob(xp, d) : logp_in[p];
+            logp_out[p] = lp0 - ladj;
+        }
+    }
+}
+
+// scratch rows: 64 floats per particle, column = hh*32 + slot  (slot m <-> accumulator (m>>4, m&15))
+__device__ __forceinline__ void store_row(float* __restrict__ dst, int64_t p, int hh, const float (&v)[32]) {
+    float4* q = reinterpret_cast<float4*>(dst + p * 64 + hh * 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+__device__ __forceinline__ void store_row(float* __restrict__ dst, int64_t p, int hh, const f32x16_t (&a)[2]) {
+    float4* q = reinterpret_cast<float4*>(dst + p * 64 + hh * 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        q[j] = make_float4(a[j >> 2][4 * (j & 3)], a[j >> 2][4 * (j & 3) + 1], a[j >> 2][4 * (j & 3) + 2],
+                           a[j >> 2][4 * (j & 3) + 3]);
+}
+
+// =========================================================================================== backward, RQS
+// scratch: ACT[L][npad][64] | GPRE[L][npad][64] | GPHI[d][npad][64],  npad = ntiles*32
+template <int K, int L>
+__global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* __restrict__ image, int d,
+                                                                   const float* __restrict__ x, int64_t n,
+                                                                   const float* __restrict__ gy,
+                                                                   const float* __restrict__ glogp,
+                                                                   float* __restrict__ gx, float* __restrict__ scratch) {
+    MF_DYN_SMEM(float, lds);
+    const ImageLayout g = image_layout(d, L, d);
+    stage_image(lds, image, g.total);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+    const int64_t ntiles = (n + 31) / 32;
+    const int64_t npad = ntiles * 32;
+    float* ACT = scratch;
+    float* GPRE = ACT + (int64_t)L * npad * 64;
+    float* GPHI = GPRE + (int64_t)L * npad * 64;
+    for (int64_t tile = (int64_t)blockIdx.x * FLOW_WAVES + wid; tile < ntiles; tile += (int64_t)gridDim.x * FLOW_WAVES) {
+        const int64_t p = tile * 32 + col;
+        const bool valid = p < n;
+        const int64_t pc = valid ? p : n - 1;
+        const float* xp = x + pc * d;
+        float xb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xb[s] = (2 * s + hh < d) ? xp[2 * s + hh] : 0.0f;
+        // ---- recompute the trunk, keep every activation
+        f32x16_t h[L][2];
+        input_layer(lds + g.offW0, lds + g.offB0, g.S0, d, xb, h[0], col, hh);
+        store_row(ACT, p, hh, h[0]);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
+            linear64(W, W + HID * WS, h[l - 1], h[l], col, hh);
+            relu2(h[l]);
+            store_row(ACT + (int64_t)l * npad * 64, p, hh, h[l]);
+        }
+        // ---- output blocks: spline forward + adjoint, accumulate dL/dh_last
+        f32x16_t gh[2];
+        f32x16_t gacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            gh[0][r] = 0.0f;
+            gh[1][r] = 0.0f;
+            gacc[r] = 0.0f;
+        }
+        const float gl = valid ? -glogp[pc] : 0.0f;
+        for (int i = 0; i < d; ++i) {
+            float v[32], gv[32];
+            const float* W3 = lds + g.offW3 + i * HID * WS;
+            block_linear(W3, lds + g.offB3 + i * HID, h[L - 1], v, col, hh);
+            const float gyi = valid ? gy[pc * d + i] : 0.0f;
+            float yi, li, gxd;
+            rqs_apply<K, true>(v, xp[i], hh, yi, li, gyi, gl, gv, gxd);
+            // direct path dL/dx_i goes into row i of the dL/dx accumulator tile (row = 4*hh + reg for rows < 8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
+            store_row(GPHI + (int64_t)i * npad * 64, p, hh, gv);
+            // gh += W3_i^T gphi   (contraction over the 64 padded output rows = slots of both halves)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                f32x16_t acc = gh[rt];
+                const float* wcol = W3 + 4 * hh * WS + 32 * rt + col;
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+                    const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
+                    acc = mfma(wcol[kk * WS], gv[s], acc);
+                }
+                gh[rt] = acc;
+            }
+        }
+        // ---- trunk backward
+#pragma unroll
+        for (int l = L - 1; l >= 1; --l) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gh[rt][r] = (h[l][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
+            store_row(GPRE + (int64_t)l * npad * 64, p, hh, gh);
+            f32x16_t t[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                t[0][r] = 0.0f;
+                t[1][r] = 0.0f;
+            }
+            linear64_t(lds + g.offWh + (l - 1) * (HID * WS + HID), gh, t, col, hh);
+            gh[0] = t[0];
+            gh[1] = t[1];
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gh[rt][r] = (h[0][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
+        store_row(GPRE, p, hh, gh);
+        if (gx != nullptr) {
+            // gacc += W0^T gpre0 : rows = input features (lanes col < d carry weights, others 0)
+            const float* wcol = lds + g.offW0 + 4 * hh * g.S0 + col;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
+                const float a = (col < d) ? wcol[kk * g.S0] : 0.0f;
+                gacc = mfma(a, gh[s >> 4][s & 15], gacc);
+            }
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * hh + j < d) gx[p * d + 4 * hh + j] = gacc[j];
+            }
+        }
+    }
+}
+
+// =========================================================================================== parameter gradients
+// C[a][b] = sum_p A[p][a] * B[p][b] over particles (MFMA k = particle), bias[a] = sum_p A[p][a].
+// grid (G, njobs); job 0: A = GPRE[0], B = x (d columns); job j in 1..L-1: A = GPRE[j], B = ACT[j-1];
+// job L+i: A = GPHI[i], B = ACT[L-1].  Results are added (float atomics) into gimage in image coordinates.
+constexpr int OA_BLOCK = 256;
+__global__ __launch_bounds__(OA_BLOCK) void outer_accum_kernel(const float* __restrict__ scratch,
+                                                               const float* __restrict__ x, int64_t n, int d, int L,
+                                                               int nblk, float* __restrict__ gimage) {
+    __shared__ float tileC[64 * 64];
+    __shared__ float tileB[64];
+    const ImageLayout g = image_layout(d, L, nblk);
+    const int64_t ntiles = (n + 31) / 32;
+    const int64_t npad = ntiles * 32;
+    const float* ACT = scratch;
+    const float* GPRE = ACT + (int64_t)L * npad * 64;
+    const float* GPHI = GPRE + (int64_t)L * npad * 64;
+    const int job = blockIdx.y;
+    const float* A;
+    const float* B = nullptr;
+    int offW, offB, strideW;
+    if (job == 0) {
+        A = GPRE;
+        offW = g.offW0; offB = g.offB0; strideW = g.S0;
+    } else if (job < L) {
+        A = GPRE + (int64_t)job * npad * 64;
+        B = ACT + (int64_t)(job - 1) * npad * 64;
+        offW = g.offWh + (job - 1) * (HID * WS + HID); offB = offW + HID * WS; strideW = WS;
+    } else {
+        const int i = job - L;
+        A = GPHI + (int64_t)i * npad * 64;
+        B = ACT + (int64_t)(L - 1) * npad * 64;
+        offW = g.offW3 + i * HID * WS; offB = g.offB3 + i * HID; strideW = WS;
+    }
+    for (int i = threadIdx.x; i < 64 * 64; i += OA_BLOCK) tileC[i] = 0.0f;
+    if (threadIdx.x < 64) tileB[threadIdx.x] = 0.0f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+    // particle pairs (k-steps) are dealt round-robin to the waves of the grid
+    const int64_t nsteps = npad / 2;
+    const int64_t wave_global = (int64_t)blockIdx.x * (OA_BLOCK / 64) + wid;
+    const int64_t wave_count = (int64_t)gridDim.x * (OA_BLOCK / 64);
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float bsum0 = 0.0f, bsum1 = 0.0f;
+    for (int64_t s = wave_global; s < nsteps; s += wave_count) {
+        const int64_t p = 2 * s + hh;
+        const float a0 = A[p * 64 + col], a1 = A[p * 64 + 32 + col];
+        float b0, b1;
+        if (job == 0) {
+            b0 = (col < d && p < n) ? x[p * d + col] : 0.0f;
+            b1 = 0.0f;
+        } else {
+            b0 = B[p * 64 + col];
+            b1 = B[p * 64 + 32 + col];
+        }
+        bsum0 += a0;
+        bsum1 += a1;
+        acc[0][0] = mfma(a0, b0, acc[0][0]);
+        acc[1][0] = mfma(a1, b0, acc[1][0]);
+        if (job != 0) {
+            acc[0][1] = mfma(a0, b1, acc[0][1]);
+            acc[1][1] = mfma(a1, b1, acc[1][1]);
+        }
+    }
+    // memory column c = hhc*32 + m  <->  physical row rho = 32*(m>>4) + rowmap(m&15, hhc)
+    const int mB = col;   // b_mem = 32*tb + col -> hhc = tb, m = col
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const int rhoB = (job == 0) ? col : (32 * (mB >> 4) + rowmap(mB & 15, tb));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mA = rowmap(r, hh);                       // a_mem = 32*ta + mA -> hhc = ta, m = mA
+                const int rhoA = 32 * (mA >> 4) + rowmap(mA & 15, ta);
+                if (job != 0 || tb == 0) atomicAdd(&tileC[rhoA * 64 + rhoB], acc[ta][tb][r]);
+            }
+        }
+    {
+        const int rho0 = 32 * (col >> 4) + rowmap(col & 15, 0);
+        const int rho1 = 32 * (col >> 4) + rowmap(col & 15, 1);
+        atomicAdd(&tileB[rho0], bsum0);
+        atomicAdd(&tileB[rho1], bsum1);
+    }
+    __syncthreads();
+    const int ncolsB = (job == 0) ? d : 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += OA_BLOCK) {
+        const int ra = i >> 6, cb = i & 63;
+        if (cb < ncolsB) atomicAdd(&gimage[offW + ra * strideW + cb], tileC[i]);
+    }
+    if (threadIdx.x < 64) atomicAdd(&gimage[offB + threadIdx.x], tileB[threadIdx.x]);
+}
+
+static int flow_check(int d, int L, int64_t n) {
+    if (d < 1 || d > FLOW_DMAX) return fail("flow kernels support 1 <= d <= %d (got %d)", FLOW_DMAX, d);
+    if (L < 1) return fail("hidden_layers must be >= 1");
+    if (n < 0) return fail("negative particle count");
+    return 0;
+}
+
+static int flow_grid(int64_t n) {
+    const int64_t ntiles = (n + 31) / 32;
+    int64_t g = (ntiles + FLOW_WAVES - 1) / FLOW_WAVES;
+    if (g > NUM_CU) g = NUM_CU;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" int64_t mf_flow_image_floats(int d, int hidden_layers) { return image_layout(d, hidden_layers, d).total; }
+
+extern "C" int64_t mf_flow_bwd_scratch_floats(int64_t n, int d, int hidden_layers) {
+    const int64_t npad = ((n + 31) / 32) * 32;
+    return (2 * (int64_t)hidden_layers + d) * npad * 64;
+}
+
+#define MF_RQS_CASES(X) X(20, 3) X(20, 2) X(8, 3) X(8, 2)
+
+extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layers, int bins, const float* x, int64_t n,
+                                      float* y, const float* logp_in, float* logp_out, int init_logp, void* stream) {
+    if (flow_check(d, hidden_layers, n)) return 1;
+    if (n == 0) return 0;
+    const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, d).total;
+#define X(KK, LL)                                                                                                     \
+    if (bins == KK && hidden_layers == LL) {                                                                          \
+        MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL>), smem);                                                      \
+        MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL>), flow_grid(n), FLOW_BLOCK, smem, stream, image, d, x, n, y, logp_in,  \
+                  logp_out, init_logp);                                                                               \
+        return check_launch("mf_flow_rqs_layer_fwd");                                                                 \
+    }
+    MF_RQS_CASES(X)
+#undef X
+    return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: bins in {8,20}, hidden_layers in {2,3})", bins,
+                hidden_layers);
+}
+
+extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins, const float* x, int64_t n,
+                                      const float* gy, const float* glogp, float* gx, float* gimage, float* scratch,
+                                      int64_t scratch_floats, void* stream) {
+    if (flow_check(d, hidden_layers, n)) return 1;
+    if (n == 0) return 0;
+    if (scratch_floats < mf_flow_bwd_scratch_floats(n, d, hidden_layers)) return fail("scratch too small");
+    const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, d).total;
+    bool launched = false;
+#define X(KK, LL)                                                                                                     \
+    if (!launched && bins == KK && hidden_layers == LL) {                                                             \
+        MF_ALLOW_DYN_SMEM((rqs_layer_bwd_kernel<KK, LL>), smem);                                                      \
+        MF_LAUNCH((rqs_layer_bwd_kernel<KK, LL>), flow_grid(n), FLOW_BLOCK, smem, stream, image, d, x, n, gy, glogp,   \
+                  gx, scratch);                                                                                       \
+        launched = true;                                                                                              \
+    }
+    MF_RQS_CASES(X)
+#undef X
+    if (!launched)
+        return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: bins in {8,20}, hidden_layers in {2,3})",
+                    bins, hidden_layers);
+    if (check_launch("mf_flow_rqs_layer_bwd")) return 1;
+    const int64_t npad = ((n + 31) / 32) * 32;
+    int64_t G = npad / 2 / 64;
+    if (G < 1) G = 1;
+    if (G > 128) G = 128;
+    const int njobs = hidden_layers + d;
+    MF_LAUNCH(outer_accum_kernel, dim3((unsigned)G, njobs), OA_BLOCK, 0, stream, (const float*)scratch, x, n, d,
+              hidden_layers, d, gimage);
+    return check_launch("mf_flow_rqs_layer_bwd(outer_accum)");
+}

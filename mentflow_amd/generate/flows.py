@@ -1,0 +1,179 @@
+"""Autoregressive normalizing flows (NSF / MAF) on the gfx950 kernels.
+
+Drop-in for ``mentflow.generate.flows.WrappedZukoFlow`` (mentflow/generate/flows/zuko.py:10-53) wrapping a zuko
+``NSF``/``MAF`` inverted as in mentflow/generate/build.py:42-43.  The module tree reproduces zuko 1.3.1's, so that
+``state_dict()`` keys have the same names ([MEM] — zuko is not available to check):
+
+    _flow.transform.transform.transforms.{t}.hyper.{0,2,4,...}.{weight,bias,mask}
+    _flow.transform.transform.transforms.{t}.order
+    _flow.base._0, _flow.base._1
+
+Parameters are ordinary ``nn.Linear`` weights (same default init, same construction order as zuko's MaskedMLP);
+every call packs them (one gather kernel) into the per-layer LDS images the kernels consume.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import get_lib
+from .base import GenerativeModel
+from .masks import conditioner_masks
+from . import packing
+
+
+class MaskedLinear(nn.Linear):
+    """zuko.nn.MaskedLinear: linear layer whose weight is multiplied by a constant 0/1 mask."""
+
+    def __init__(self, adjacency: torch.Tensor):
+        super().__init__(adjacency.shape[1], adjacency.shape[0])
+        self.register_buffer("mask", adjacency)
+
+
+class MaskedAutoregressiveTransform(nn.Module):
+    """Parameter holder of one autoregressive layer (zuko MaskedAutoregressiveTransform)."""
+
+    def __init__(self, features: int, order: torch.Tensor, hidden_features: Sequence[int], total: int):
+        super().__init__()
+        self.register_buffer("order", order)
+        masks = conditioner_masks(order, hidden_features, total)
+        layers: List[nn.Module] = []
+        for i, m in enumerate(masks):
+            layers.append(MaskedLinear(m))
+            if i < len(masks) - 1:
+                layers.append(nn.ReLU())
+        self.hyper = nn.Sequential(*layers)
+
+    def linears(self) -> List[MaskedLinear]:
+        return [m for m in self.hyper if isinstance(m, MaskedLinear)]
+
+
+class _Composed(nn.Module):
+    def __init__(self, transforms: Sequence[nn.Module]):
+        super().__init__()
+        self.transforms = nn.ModuleList(transforms)
+
+
+class _Inverse(nn.Module):
+    def __init__(self, transform: nn.Module):
+        super().__init__()
+        self.transform = transform
+
+
+class _DiagNormalBase(nn.Module):
+    def __init__(self, features: int):
+        super().__init__()
+        self.register_buffer("_0", torch.zeros(features))
+        self.register_buffer("_1", torch.ones(features))
+
+
+class _Flow(nn.Module):
+    def __init__(self, transform: nn.Module, base: nn.Module):
+        super().__init__()
+        self.transform = transform
+        self.base = base
+
+
+class AutoregressiveFlow(GenerativeModel):
+    """NSF ("rqs") or MAF ("affine") generator with the reference's ``GenerativeModel`` API."""
+
+    def __init__(self, features: int, hidden_features: Sequence[int] = (64, 64, 64), transforms: int = 5,
+                 kind: str = "rqs", bins: int = 20):
+        super().__init__()
+        if kind not in ("rqs", "affine"):
+            raise ValueError(kind)
+        if any(h != packing.HID for h in hidden_features):
+            raise NotImplementedError("the gfx950 flow kernels are built for hidden_units=64 (reference default)")
+        self.features, self.kind, self.bins = int(features), kind, int(bins)
+        self.hidden_features = tuple(int(h) for h in hidden_features)
+        self.total = 3 * self.bins - 1 if kind == "rqs" else 2
+        orders = [torch.arange(features), torch.flipud(torch.arange(features))]
+        layers = [MaskedAutoregressiveTransform(features, orders[t % 2].clone(), self.hidden_features, self.total)
+                  for t in range(transforms)]
+        self._flow = _Flow(_Inverse(_Composed(layers)), _DiagNormalBase(features))
+        self._spec: Optional[ops.FlowSpec] = None
+        self._spec_device = None
+        self.grad_reduce = None          # set by mentflow_amd.dist for data-parallel runs
+        self.inject_z: Optional[torch.Tensor] = None   # parity tests: base draw used instead of a fresh one
+
+    # ------------------------------------------------------------------ packing
+    @property
+    def layers(self) -> List[MaskedAutoregressiveTransform]:
+        return list(self._flow.transform.transform.transforms)
+
+    def flat_parameters(self) -> torch.Tensor:
+        return torch.cat([p.reshape(-1) for p in self.parameters()])
+
+    def build_index_maps(self) -> Tuple[np.ndarray, np.ndarray, int]:
+        """(image_index [T*image_floats], grad_index [numel], image_floats) — pure host logic."""
+        d, L = self.features, len(self.hidden_features)
+        offsets, off = [], 0
+        for p in self.parameters():
+            offsets.append(off)
+            off += p.numel()
+        numel = off
+        per_layer = 2 * (L + 1)
+        idx = []
+        for t, layer in enumerate(self.layers):
+            masks = [lin.mask.cpu() for lin in layer.linears()]
+            idx.append(packing.layer_image_index(d, L, self.kind, self.bins, masks,
+                                                 offsets[t * per_layer:(t + 1) * per_layer]))
+        image_index = np.concatenate(idx)
+        return image_index, packing.invert_index(image_index, numel), idx[0].size
+
+    def spec(self) -> ops.FlowSpec:
+        dev = next(self.parameters()).device
+        if self._spec is None or self._spec_device != dev:
+            image_index, grad_index, image_floats = self.build_index_maps()
+            lib = get_lib()
+            expect = (lib.mf_flow_image_floats(self.features, len(self.hidden_features)) if self.kind == "rqs"
+                      else lib.mf_flow_affine_image_floats(self.features, len(self.hidden_features)))
+            if expect != image_floats:
+                raise RuntimeError(f"image layout mismatch: host {image_floats} vs library {expect}")
+            self._spec = ops.FlowSpec(self.features, len(self.hidden_features), len(self.layers), self.kind, self.bins,
+                                      image_floats, torch.from_numpy(image_index).to(dev),
+                                      torch.from_numpy(grad_index).to(dev))
+            self._spec_device = dev
+        return self._spec
+
+    # ------------------------------------------------------------------ GenerativeModel API (flows/zuko.py:15-53)
+    def dim(self) -> int:
+        return self.features
+
+    def sample_base(self, n: int) -> torch.Tensor:
+        dev = next(self.parameters()).device
+        return torch.randn((int(n), self.features), device=dev)
+
+    def sample_and_log_prob(self, n: int, z: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """x = F(z), log_prob = logN(z) - ladj.  ``z`` may be injected (parity tests); default: fresh base draw."""
+        if z is None:
+            z = self.inject_z if self.inject_z is not None else self.sample_base(n)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return ops.FlowSampleFn.apply(z, self.flat_parameters(), self.spec(), self.grad_reduce)
+        xs, logp = ops.flow_layers_forward(z, self.flat_parameters(), self.spec())
+        return xs[-1], logp
+
+    def sample(self, n: int) -> torch.Tensor:
+        return self.sample_and_log_prob(n)[0]
+
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        return self.sample_and_log_prob(z.shape[0], z=z)[0]
+
+    def forward_steps(self, z: torch.Tensor) -> List[torch.Tensor]:
+        with torch.no_grad():
+            xs, _ = ops.flow_layers_forward(z.clone(), self.flat_parameters(), self.spec())
+        return xs
+
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError("density of an arbitrary point needs the d-pass autoregressive inversion "
+                                  "(SURVEY.md §8f-3, 'next' tier): not built yet")
+
+    def inverse(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError("autoregressive inversion (SURVEY.md §8f-3, 'next' tier): not built yet")
+
+    def inverse_steps(self, x: torch.Tensor) -> List[torch.Tensor]:
+        raise NotImplementedError("autoregressive inversion (SURVEY.md §8f-3, 'next' tier): not built yet")

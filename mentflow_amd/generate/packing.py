@@ -1,0 +1,112 @@
+"""Host-side index maps between the flat parameter vector of a flow and the per-layer LDS weight images the
+gfx950 kernels consume (layout documented in include/mentflow_hip.h and mentflow_amd/csrc/flow.hip).
+
+image (floats), hidden width 64, ``nblk`` output blocks of 64 padded rows (RQS: one block per feature; affine: 1):
+    [W0   : 64 x S0 ]  S0 = d | 1 (odd row stride)           input layer, natural [out][in]
+    [b0   : 64      ]
+    {[W_l : 64 x 65 ][b_l : 64]}  l = 1 .. L-1                hidden layers, natural [out][in], stride 65
+    [Wout : nblk x 64 x 65]                                   last layer, ROWS PERMUTED (below)
+    [bout : nblk x 64]
+
+Masked-out weights and padding carry index -1 (the gather writes 0 there) — this is where zuko's
+``mask * weight`` (MaskedLinear.forward) happens: once per optimizer step, not once per call.
+
+Row permutation of the last layer.  The kernels evaluate the spline of feature i in the two lanes (col, col+32) of
+a particle; a lane half hh holds, in accumulator slot m (0..31), the MFMA row
+    rho(hh, m) = 32*(m >> 4) + (m & 3) + 8*((m & 15) >> 2) + 4*hh.
+RQS, K bins, KD0 = K // 2:   half 0: slots 0..K-1 = widths, K..K+KD0-1 = derivatives 0..KD0-1
+                             half 1: slots 0..K-1 = heights, K..      = derivatives KD0..K-2
+affine:                      half 0: slot i = shift_i;  half 1: slot i = scale_i      (single block)
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+HID = 64
+WS = HID + 1
+
+
+def rho(hh: int, m: int) -> int:
+    return 32 * (m >> 4) + (m & 3) + 8 * ((m & 15) >> 2) + 4 * hh
+
+
+def slot_of_row(r: int) -> Tuple[int, int]:
+    """inverse of rho: physical row (0..63) -> (hh, slot m)."""
+    rr = r & 31
+    hh = (rr >> 2) & 1
+    m = 16 * (r >> 5) + (rr & 3) + 4 * (rr >> 3)
+    return hh, m
+
+
+def image_layout(d: int, L: int, nblk: int) -> dict:
+    S0 = d | 1
+    g = {"S0": S0, "offW0": 0}
+    g["offB0"] = HID * S0
+    g["offWh"] = g["offB0"] + HID
+    g["offW3"] = g["offWh"] + (L - 1) * (HID * WS + HID)
+    g["offB3"] = g["offW3"] + nblk * HID * WS
+    g["total"] = g["offB3"] + nblk * HID
+    return g
+
+
+def rqs_logical_param(hh: int, m: int, K: int) -> int:
+    """index (0..3K-2) of the spline parameter held in slot m of lane half hh, or -1 if the slot is unused."""
+    KD0 = K // 2
+    if m < K:
+        return m if hh == 0 else K + m
+    j = m - K
+    if hh == 0:
+        return 2 * K + j if j < KD0 else -1
+    return 2 * K + KD0 + j if j < (K - 1 - KD0) else -1
+
+
+def layer_image_index(d: int, L: int, kind: str, K: int, masks: Sequence[torch.Tensor], offsets: Sequence[int]) -> np.ndarray:
+    """int32 [image_floats]: index into the flat parameter vector (or -1).
+
+    masks: bool [out,in] per linear layer (L+1 of them); offsets: flat offset of W_0, b_0, W_1, b_1, ... (2(L+1)).
+    """
+    total_per_feature = 3 * K - 1 if kind == "rqs" else 2
+    nblk = d if kind == "rqs" else 1
+    g = image_layout(d, L, nblk)
+    idx = np.full(g["total"], -1, dtype=np.int64)
+    m0 = masks[0].numpy()
+    for u in range(HID):
+        for j in range(d):
+            if m0[u, j]:
+                idx[g["offW0"] + u * g["S0"] + j] = offsets[0] + u * d + j
+        idx[g["offB0"] + u] = offsets[1] + u
+    for l in range(1, L):
+        ml = masks[l].numpy()
+        base = g["offWh"] + (l - 1) * (HID * WS + HID)
+        for u in range(HID):
+            for k in range(HID):
+                if ml[u, k]:
+                    idx[base + u * WS + k] = offsets[2 * l] + u * HID + k
+            idx[base + HID * WS + u] = offsets[2 * l + 1] + u
+    mo = masks[L].numpy()
+    for blk in range(nblk):
+        for r in range(HID):
+            hh, m = slot_of_row(r)
+            if kind == "rqs":
+                t = rqs_logical_param(hh, m, K)
+                row = blk * total_per_feature + t if t >= 0 else -1
+            else:
+                row = (2 * m + hh) if m < d else -1       # feature m: (shift, scale) = rows 2m, 2m+1
+            if row < 0:
+                continue
+            for k in range(HID):
+                if mo[row, k]:
+                    idx[g["offW3"] + (blk * HID + r) * WS + k] = offsets[2 * L] + row * HID + k
+            idx[g["offB3"] + blk * HID + r] = offsets[2 * L + 1] + row
+    return idx.astype(np.int32)
+
+
+def invert_index(image_index: np.ndarray, numel: int) -> np.ndarray:
+    """int32 [numel]: position in the (concatenated) image of every flat parameter, -1 if it is masked out."""
+    inv = np.full(numel, -1, dtype=np.int64)
+    pos = np.nonzero(image_index >= 0)[0]
+    inv[image_index[pos]] = pos
+    return inv.astype(np.int32)

@@ -1,0 +1,268 @@
+"""torch.autograd wrappers over the C ABI of libmentflow_hip.so (include/mentflow_hip.h).
+
+Each Function's forward AND backward is a hand-written gfx950 kernel; torch supplies device memory, the current
+stream and the autograd graph between ops, nothing else.  All tensors must live on the GPU (mentflow_amd._lib.ptr
+raises otherwise): there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
+_F32 = torch.float32
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != _F32:
+        raise RuntimeError(f"mentflow_amd kernels compute in float32 (got {t.dtype})")
+    return t.contiguous()
+
+
+def kde_radius(bandwidth_in_bins: float) -> int:
+    """Truncation radius (bins) of the Gaussian KDE: weights beyond (R + 1/2) bins are < exp(-40.5) = 2.6e-18."""
+    return max(1, int(math.ceil(9.0 * float(bandwidth_in_bins) - 0.5)))
+
+
+# ------------------------------------------------------------------------------------------------ flow
+class FlowSpec:
+    """Static description of a packed flow (shared by every call): geometry + device index maps."""
+
+    def __init__(self, d: int, hidden_layers: int, transforms: int, kind: str, bins: int, image_floats: int,
+                 image_index: torch.Tensor, grad_index: torch.Tensor):
+        self.d, self.L, self.T, self.kind, self.bins = d, hidden_layers, transforms, kind, bins
+        self.image_floats = image_floats
+        self.image_index = image_index      # int32 [T * image_floats]  -> flat parameter index or -1
+        self.grad_index = grad_index        # int32 [numel]             -> position in the image stack or -1
+        self.bwd_chunk = 1 << 19            # particles per backward chunk (3 KiB of scratch each at d=6)
+
+
+def _layer_fwd(spec: FlowSpec, image: torch.Tensor, x: torch.Tensor, y: torch.Tensor, logp_in: Optional[torch.Tensor],
+               logp_out: torch.Tensor, init: bool) -> None:
+    n = x.shape[0]
+    if spec.kind == "rqs":
+        call("mf_flow_rqs_layer_fwd", ptr(image), spec.d, spec.L, spec.bins, ptr(x), n, ptr(y), ptr(logp_in),
+             ptr(logp_out), int(init), stream_ptr(x))
+    else:
+        call("mf_flow_affine_layer_fwd", ptr(image), spec.d, spec.L, ptr(x), n, ptr(y), ptr(logp_in), ptr(logp_out),
+             int(init), stream_ptr(x))
+
+
+def _layer_bwd(spec: FlowSpec, image, x, gy, glogp, gx, gimage, scratch) -> None:
+    n = x.shape[0]
+    if spec.kind == "rqs":
+        call("mf_flow_rqs_layer_bwd", ptr(image), spec.d, spec.L, spec.bins, ptr(x), n, ptr(gy), ptr(glogp), ptr(gx),
+             ptr(gimage), ptr(scratch), scratch.numel(), stream_ptr(x))
+    else:
+        call("mf_flow_affine_layer_bwd", ptr(image), spec.d, spec.L, ptr(x), n, ptr(gy), ptr(glogp), ptr(gx),
+             ptr(gimage), ptr(scratch), scratch.numel(), stream_ptr(x))
+
+
+def pack_images(spec: FlowSpec, flat: torch.Tensor) -> torch.Tensor:
+    images = torch.empty(spec.T * spec.image_floats, dtype=_F32, device=flat.device)
+    call("mf_gather_f32", ptr(flat), ptr(spec.image_index), ptr(images), images.numel(), 0, stream_ptr(flat))
+    return images.view(spec.T, spec.image_floats)
+
+
+class FlowSampleFn(torch.autograd.Function):
+    """(z[N,d], flat parameters) -> (x[N,d], log_prob[N]) through all T autoregressive layers.
+
+    Replaces zuko ``NormalizingFlow.rsample_and_log_prob`` as called by
+    mentflow/generate/flows/zuko.py:24-26 (base draw z injected) and its autograd backward.
+    Saved for backward: the T layer inputs (N x d each) and the packed images; everything else is recomputed.
+    """
+
+    @staticmethod
+    def forward(ctx, z: torch.Tensor, flat: torch.Tensor, spec: FlowSpec, grad_reduce=None):
+        z = _f32c(z)
+        flat = _f32c(flat)
+        n = z.shape[0]
+        images = pack_images(spec, flat)
+        logp = torch.empty(n, dtype=_F32, device=z.device)
+        xs = [z]
+        for t in range(spec.T):
+            y = torch.empty_like(z)
+            _layer_fwd(spec, images[t], xs[-1], y, logp, logp, t == 0)
+            xs.append(y)
+        ctx.spec = spec
+        ctx.grad_reduce = grad_reduce
+        ctx.save_for_backward(images, *xs[:-1])
+        ctx.mark_non_differentiable()
+        return xs[-1], logp
+
+    @staticmethod
+    def backward(ctx, gx: Optional[torch.Tensor], glogp: Optional[torch.Tensor]):
+        spec: FlowSpec = ctx.spec
+        images, *xs = ctx.saved_tensors
+        n = xs[0].shape[0]
+        dev = images.device
+        gx = torch.zeros(n, spec.d, dtype=_F32, device=dev) if gx is None else _f32c(gx)
+        glogp = torch.zeros(n, dtype=_F32, device=dev) if glogp is None else _f32c(glogp)
+        gimages = torch.zeros_like(images)
+        chunk = min(n, spec.bwd_chunk)
+        scratch_floats = _lib.get_lib().mf_flow_bwd_scratch_floats(chunk, spec.d, spec.L)
+        scratch = torch.empty(max(scratch_floats, 1), dtype=_F32, device=dev)
+        g = gx
+        for t in reversed(range(spec.T)):
+            gprev = torch.empty_like(g) if t > 0 else None
+            for a in range(0, n, chunk):
+                b = min(n, a + chunk)
+                _layer_bwd(spec, images[t], xs[t][a:b], g[a:b], glogp[a:b], None if gprev is None else gprev[a:b],
+                           gimages[t], scratch)
+            g = gprev
+        gflat = torch.empty(spec.grad_index.numel(), dtype=_F32, device=dev)
+        call("mf_gather_f32", ptr(gimages.view(-1)), ptr(spec.grad_index), ptr(gflat), gflat.numel(), 0,
+             stream_ptr(gflat))
+        if ctx.grad_reduce is not None:
+            ctx.grad_reduce(gflat)
+        return None, gflat, None, None
+
+
+def flow_layers_forward(z: torch.Tensor, flat: torch.Tensor, spec: FlowSpec) -> Tuple[List[torch.Tensor], torch.Tensor]:
+    """No-grad helper: every intermediate [z, x_1, ..., x_T] and log_prob (forward_steps / sample)."""
+    z = _f32c(z)
+    images = pack_images(spec, _f32c(flat.detach()))
+    logp = torch.empty(z.shape[0], dtype=_F32, device=z.device)
+    xs = [z]
+    for t in range(spec.T):
+        y = torch.empty_like(z)
+        _layer_fwd(spec, images[t], xs[-1], y, logp, logp, t == 0)
+        xs.append(y)
+    return xs, logp
+
+
+# ------------------------------------------------------------------------------------------------ projections + KDE
+class ProjKde1dFn(torch.autograd.Function):
+    """x[N,d], V[P,d] -> S[P,B] = sum_n exp(-((x_n.V_p - c_k)/sigma)^2 / 2)   (raw kernel sums).
+
+    Replaces the Python loop of mentflow/simulate/simulate.py:30-33 over LinearTransform.forward
+    (simulate/transform.py:67-68) + Histogram1D.project (diagnostics/diagnostics.py:116-122) + the kernel matrix of
+    marginal_pdf (diagnostics/histogram.py:37-39)."""
+
+    @staticmethod
+    def forward(ctx, x, V, coords, sigma: float, radius: int):
+        x, V, coords = _f32c(x), _f32c(V), _f32c(coords)
+        P, B = V.shape[0], coords.numel()
+        S = torch.empty(P, B, dtype=_F32, device=x.device)
+        call("mf_proj_kde1d_fwd", ptr(x), x.shape[0], x.shape[1], ptr(V), P, ptr(coords), B, float(sigma), int(radius),
+             ptr(S), stream_ptr(x))
+        ctx.save_for_backward(x, V, coords)
+        ctx.sigma, ctx.radius = float(sigma), int(radius)
+        return S
+
+    @staticmethod
+    def backward(ctx, gS):
+        x, V, coords = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        call("mf_proj_kde1d_bwd", ptr(x), x.shape[0], x.shape[1], ptr(V), V.shape[0], ptr(coords), coords.numel(),
+             ctx.sigma, ctx.radius, ptr(_f32c(gS)), ptr(gx), 0, stream_ptr(x))
+        return gx, None, None, None, None
+
+
+class ProjKde2dFn(torch.autograd.Function):
+    """x[N,d], V0[P,d], V1[P,d] -> S[P,Bx,By] = sum_n Kx_na Ky_nb  (histogram.py:89-101 / joint_pdf :69)."""
+
+    @staticmethod
+    def forward(ctx, x, V0, V1, coords_x, coords_y, sigma_x: float, sigma_y: float, radius_x: int, radius_y: int):
+        x, V0, V1, cx, cy = _f32c(x), _f32c(V0), _f32c(V1), _f32c(coords_x), _f32c(coords_y)
+        P, Bx, By = V0.shape[0], cx.numel(), cy.numel()
+        S = torch.empty(P, Bx, By, dtype=_F32, device=x.device)
+        call("mf_proj_kde2d_fwd", ptr(x), x.shape[0], x.shape[1], ptr(V0), ptr(V1), P, ptr(cx), Bx, float(sigma_x),
+             int(radius_x), ptr(cy), By, float(sigma_y), int(radius_y), ptr(S), stream_ptr(x))
+        ctx.save_for_backward(x, V0, V1, cx, cy)
+        ctx.args = (float(sigma_x), float(sigma_y), int(radius_x), int(radius_y))
+        return S
+
+    @staticmethod
+    def backward(ctx, gS):
+        x, V0, V1, cx, cy = ctx.saved_tensors
+        sx, sy, rx, ry = ctx.args
+        gx = torch.empty_like(x)
+        call("mf_proj_kde2d_bwd", ptr(x), x.shape[0], x.shape[1], ptr(V0), ptr(V1), V0.shape[0], ptr(cx), cx.numel(), sx,
+             rx, ptr(cy), cy.numel(), sy, ry, ptr(_f32c(gS)), ptr(gx), 0, stream_ptr(x))
+        return gx, None, None, None, None, None, None, None, None
+
+
+DISCREPANCY_KINDS = {"kld": 0, "mae": 1, "mse": 2}
+
+
+class HistNormDiscFn(torch.autograd.Function):
+    """S[P,bins] (+ meas[P,bins]) -> (ghat[P,bins], D[P]).
+
+    normalize: marginal_pdf / joint_pdf normalisation (histogram.py:39-43, :69-73);
+    discrepancy: mentflow/loss.py:7-17.  With meas=None only ghat is produced (D is an empty tensor)."""
+
+    @staticmethod
+    def forward(ctx, S, meas, normalize: bool, pre_scale: float, cell: float, eps: float, kind: int, pad: float,
+                batch_div: float):
+        S = _f32c(S)
+        P = S.shape[0]
+        bins = S[0].numel()
+        meas_c = None if meas is None else _f32c(meas)
+        ghat = torch.empty_like(S)
+        D = torch.empty(P if meas is not None else 0, dtype=_F32, device=S.device)
+        call("mf_hist_norm_discrepancy_fwd", ptr(S), P, bins, int(normalize), float(pre_scale), float(cell), float(eps),
+             ptr(meas_c), int(kind), float(pad), float(batch_div), ptr(ghat), ptr(D) if meas is not None else None,
+             stream_ptr(S))
+        ctx.save_for_backward(S, meas_c) if meas is not None else ctx.save_for_backward(S)
+        ctx.has_meas = meas is not None
+        ctx.args = (int(normalize), float(pre_scale), float(cell), float(eps), int(kind), float(pad), float(batch_div))
+        return ghat, D
+
+    @staticmethod
+    def backward(ctx, gghat, gD):
+        if ctx.has_meas:
+            S, meas = ctx.saved_tensors
+        else:
+            (S,) = ctx.saved_tensors
+            meas, gD = None, None
+        normalize, pre_scale, cell, eps, kind, pad, batch_div = ctx.args
+        gS = torch.empty_like(S)
+        gD_c = None if gD is None else _f32c(gD)
+        gg_c = None if gghat is None else _f32c(gghat)
+        call("mf_hist_norm_discrepancy_bwd", ptr(S), S.shape[0], S[0].numel(), normalize, pre_scale, cell, eps, ptr(meas),
+             kind, pad, batch_div, ptr(gD_c), ptr(gg_c), ptr(gS), stream_ptr(S))
+        return gS, None, None, None, None, None, None, None, None
+
+
+class EntropySumsFn(torch.autograd.Function):
+    """(x[N,d], logp[N]) -> [sum logp, sum |x|^2]  (entropy.py:58-62, prior.py:25-26)."""
+
+    @staticmethod
+    def forward(ctx, x, logp):
+        x, logp = _f32c(x), _f32c(logp)
+        out = torch.empty(2, dtype=_F32, device=x.device)
+        scratch = torch.empty(2, dtype=torch.float64, device=x.device)
+        call("mf_mc_entropy_sums", ptr(x), ptr(logp), x.shape[0], x.shape[1], ptr(out), ptr(scratch), stream_ptr(x))
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x,) = ctx.saved_tensors
+        gout = _f32c(gout)
+        gx = torch.empty_like(x)
+        call("mf_scale_rows", ptr(x), x.shape[0], x.shape[1], ptr(gout[1:2]), 2.0, ptr(gx), 0, stream_ptr(x))
+        glogp = gout[0].expand(x.shape[0]).contiguous()
+        return gx, glogp
+
+
+def proj_hist_counts_1d(x, V, edges) -> torch.Tensor:
+    x, V, edges = _f32c(x), _f32c(V), _f32c(edges)
+    P, B = V.shape[0], edges.numel() - 1
+    counts = torch.empty(P, B, dtype=torch.int32, device=x.device)
+    call("mf_proj_hist1d_counts", ptr(x), x.shape[0], x.shape[1], ptr(V), P, ptr(edges), B, ptr(counts), stream_ptr(x))
+    return counts
+
+
+def proj_hist_counts_2d(x, V0, V1, edges_x, edges_y) -> torch.Tensor:
+    x, V0, V1, ex, ey = _f32c(x), _f32c(V0), _f32c(V1), _f32c(edges_x), _f32c(edges_y)
+    P, Bx, By = V0.shape[0], ex.numel() - 1, ey.numel() - 1
+    counts = torch.empty(P, Bx, By, dtype=torch.int32, device=x.device)
+    call("mf_proj_hist2d_counts", ptr(x), x.shape[0], x.shape[1], ptr(V0), ptr(V1), P, ptr(ex), Bx, ptr(ey), By,
+         ptr(counts), stream_ptr(x))
+    return counts

@@ -1,0 +1,25 @@
+"""Prior distributions — mirrors mentflow/prior.py:4-26."""
+import math
+
+import torch
+
+
+class Gaussian:
+    """Isotropic Gaussian prior N(0, scale^2 I).  ``log_prob`` is the closed form of
+    ``MultivariateNormal(0, scale^2 I).log_prob`` (prior.py:25-26); inside ``MonteCarloEntropyEstimator`` only its
+    sufficient statistic sum|x|^2 is needed, which the entropy kernel reduces."""
+
+    def __init__(self, ndim: int = 2, scale: float = 1.0, device=None) -> None:
+        self.ndim = ndim
+        self.scale = scale
+        self.device = device
+
+    def to(self, device):
+        self.device = device
+        return self
+
+    def log_norm(self) -> float:
+        return -self.ndim * math.log(self.scale) - 0.5 * self.ndim * math.log(2.0 * math.pi)
+
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        return -0.5 * torch.sum(x * x, dim=1) / (self.scale ** 2) + self.log_norm()

@@ -1,0 +1,111 @@
+"""Flow kernels (through the C ABI + mentflow-compatible generator API) against the oracle restatement
+(oracle/flow.py — parity unpinned, see its header) on identical weights and injected base draws z.
+
+fp32 tolerances: x atol 5e-5, log_prob atol 5e-4 (deliberately steep splines, |ladj| ~ 10), parameter gradients
+2e-3 of the largest gradient entry; the oracle is evaluated in fp64 where stated so that both fp32 sides are judged
+against a common, more accurate value."""
+import pytest
+import torch
+
+import mentflow_amd as mf
+from oracle import flow as of
+from oracle.harness import flow_spec_from_generator, oracle_step
+
+
+def make_generator(backend, d, kind="nsf", transforms=2, bins=20, steep=True, seed=0):
+    torch.manual_seed(seed)
+    kws = dict(input_features=d, output_features=d, hidden_layers=3, hidden_units=64, transforms=transforms)
+    if kind == "nsf":
+        kws["bins"] = bins
+    gen = mf.generate.build_generator(kind, **kws)
+    if steep:       # default init gives near-identity transforms; make the conditioner matter
+        with torch.no_grad():
+            for layer in gen.layers:
+                lin = layer.linears()[-1]
+                lin.weight.mul_(4.0)
+                lin.bias.add_(torch.randn_like(lin.bias))
+    return gen.to(backend)
+
+
+@pytest.mark.parametrize("d,bins", [(6, 20), (2, 20), (3, 8)])
+def test_nsf_forward_matches_oracle(backend, d, bins):
+    gen = make_generator(backend, d, bins=bins)
+    torch.manual_seed(1)
+    z = torch.randn(77, d) * 1.5
+    z[0, 0], z[1, d - 1], z[2, 0] = 6.0, -5.5, 5.0          # outside / on the spline domain
+    with torch.no_grad():
+        x, lp = gen.sample_and_log_prob(77, z=z.to(backend))
+        steps = gen.forward_steps(z.to(backend))
+    s64 = flow_spec_from_generator(gen, torch.float64)
+    x64, lp64 = of.sample_and_log_prob(z.double(), s64)
+    assert (x.cpu() - x64).abs().max() < 5e-5
+    assert (lp.cpu() - lp64).abs().max() < 5e-4
+    ref_steps = of.flow_forward_steps(z.double(), s64)
+    assert len(steps) == len(ref_steps) == 3
+    for a, b in zip(steps, ref_steps):
+        assert (a.cpu() - b).abs().max() < 5e-5
+    # fp32 oracle within the same band of the fp64 one (both sides are fp32 implementations)
+    x32, lp32 = of.sample_and_log_prob(z, flow_spec_from_generator(gen, torch.float32))
+    assert (x32 - x64).abs().max() < 5e-5 and (lp32 - lp64).abs().max() < 5e-4
+
+
+@pytest.mark.parametrize("d", [6, 2])
+def test_nsf_backward_matches_oracle(backend, d):
+    gen = make_generator(backend, d)
+    torch.manual_seed(2)
+    n = 70
+    z = torch.randn(n, d) * 1.5
+    wx, wl = torch.randn(n, d), torch.randn(n)
+    x, lp = gen.sample_and_log_prob(n, z=z.to(backend))
+    ((x * wx.to(backend)).sum() + (lp * wl.to(backend)).sum()).backward()
+    gk = torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).cpu()
+    s64 = flow_spec_from_generator(gen, torch.float64)
+    ps = s64.parameters()
+    for p in ps:
+        p.requires_grad_(True)
+    xo, lo = of.sample_and_log_prob(z.double(), s64)
+    ((xo * wx.double()).sum() + (lo * wl.double()).sum()).backward()
+    go = torch.cat([p.grad.reshape(-1) for p in ps])
+    assert (gk.double() - go).abs().max() < 2e-3 * go.abs().max()
+    # masked-out weights get exactly zero gradient (d(mask*W)/dW = mask)
+    off = 0
+    for layer in gen.layers:
+        for lin in layer.linears():
+            gw = lin.weight.grad.cpu()
+            assert (gw[~lin.mask.cpu()] == 0).all()
+
+
+def test_default_init_is_near_identity_and_state_dict_keys(backend):
+    gen = make_generator(backend, 6, transforms=5, steep=False)
+    keys = list(gen.state_dict().keys())
+    assert "_flow.transform.transform.transforms.0.hyper.0.weight" in keys
+    assert "_flow.transform.transform.transforms.4.hyper.6.bias" in keys
+    assert "_flow.transform.transform.transforms.1.hyper.2.mask" in keys
+    assert "_flow.transform.transform.transforms.3.order" in keys
+    assert "_flow.base._0" in keys and "_flow.base._1" in keys
+    assert sum(p.numel() for p in gen.parameters()) == 158890
+    torch.manual_seed(3)
+    z = torch.randn(64, 6)
+    with torch.no_grad():
+        x, lp = gen.sample_and_log_prob(64, z=z.to(backend))
+    x64, lp64 = of.sample_and_log_prob(z.double(), flow_spec_from_generator(gen, torch.float64))
+    assert (x.cpu() - x64).abs().max() < 1e-5 and (lp.cpu() - lp64).abs().max() < 1e-4
+
+
+def test_full_train_step_matches_oracle(backend):
+    """MENTFlow.loss() + backward, 6-D NSF x 25 projections x 64 bins, against the dense eager oracle."""
+    from mentflow_amd.harness import build_problem
+    prob = build_problem(ndim=6, num=25, bins=64, xmax=4.0, seed=2, transforms=2, prior_scale=1.0, device=backend,
+                         meas_samples=20000, penalty_parameter=500.0)
+    n = 96
+    torch.manual_seed(4)
+    z = torch.randn(n, 6)
+    prob.model.generator.inject_z = z.to(backend)
+    L, H, D = prob.model.loss(n)
+    L.backward()
+    g = torch.cat([p.grad.reshape(-1) for p in prob.model.parameters()]).cpu()
+    Lo, Ho, Do, go = oracle_step(prob, z, torch.float64)
+    assert abs(float(H) - float(Ho)) < 1e-4
+    assert (torch.stack(D).cpu() - torch.stack(Do)).abs().max() < 2e-6 + 2e-4 * float(torch.stack(Do).abs().max())
+    assert abs(float(L) - float(Lo)) < 1e-4 + 500 * 2e-6
+    assert (g.double() - go).abs().max() < 2e-3 * go.abs().max()

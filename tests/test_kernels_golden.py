@@ -1,0 +1,155 @@
+"""Parity of the kernels (through the C ABI and the mentflow-compatible Python layer) with the REFERENCE'S OWN
+outputs (tests/golden/ref_*.npz) and with the oracle.  Each test runs on the emulated host build ("emu", CPU
+container) and on the real gfx950 library ("hip", -m gpu).
+
+Tolerances (fp32, stated per SURVEY.md §8d): histograms rtol 2e-5 + atol 1e-6; H and L rtol 1e-5 (+ atol 1e-6);
+dL/dx rtol 1e-3 + atol 1e-7 * max|g|... (each assertion spells its own numbers)."""
+import numpy as np
+import pytest
+import torch
+
+import mentflow_amd as mf
+from mentflow_amd import ops
+from conftest import load_golden
+
+
+def close(a, b, rtol, atol):
+    torch.testing.assert_close(a.detach().cpu().float(), b.float(), rtol=rtol, atol=atol)
+
+
+class Injected(mf.generate.GenerativeModel):
+    """Generator stub returning fixed (x, log_prob) leaves — same trick the golden generator used."""
+
+    def __init__(self, x, logp):
+        super().__init__()
+        self.x, self.logp = x, logp
+        self._dummy = torch.nn.Parameter(torch.zeros(1))
+
+    def sample_and_log_prob(self, n):
+        return self.x, self.logp
+
+    def sample(self, n):
+        return self.x
+
+
+@pytest.mark.parametrize("bins", [64, 85])
+def test_kde1d_vs_reference(backend, bins):
+    g = load_golden(f"ref_kde1d_B{bins}")
+    u = g["u"].to(backend)[:, None].clone().requires_grad_(True)          # N x 1 "phase space"
+    diag = mf.diagnostics.Histogram1D(edges=g["edges"], bandwidth=0.5, axis=0).to(backend)
+    hist = diag(u)
+    (hist * g["w"].to(backend)).sum().backward()
+    close(hist, g["hist"], 2e-5, 1e-6)
+    close(u.grad[:, 0], g["grad_u"], 1e-3, 2e-6)
+    # standalone sanity: normalisation sum(ghat)*delta = 1
+    assert abs(float(hist.sum() * diag.resolution) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("bins", [64, 85])
+def test_kde2d_vs_reference(backend, bins):
+    g = load_golden(f"ref_kde2d_B{bins}")
+    u = g["u"].to(backend).clone().requires_grad_(True)
+    diag = mf.diagnostics.Histogram2D(axis=(0, 1), edges=(g["edges_x"], g["edges_y"]), bandwidth=(0.5, 0.5)).to(backend)
+    hist = diag(u)
+    (hist * g["w"].to(backend)).sum().backward()
+    close(hist, g["hist"], 2e-5, 1e-7)
+    close(u.grad, g["grad_u"], 1e-3, 2e-6)
+
+
+def test_hard_histograms_vs_reference(backend):
+    g = load_golden("ref_hist_hard")
+    x = g["x"].to(backend)
+    d1 = mf.diagnostics.Histogram1D(edges=g["edges1"], bandwidth=0.5, axis=0, kde=False).to(backend)
+    h1 = d1(x)
+    close(h1, g["hist1"], 1e-6, 1e-7)
+    counts = ops.proj_hist_counts_1d(x, torch.eye(6, device=backend)[:1].contiguous(), g["edges1"].to(backend))
+    ref_counts = torch.histogram(g["x"][:, 0], g["edges1"]).hist
+    assert torch.equal(counts[0].cpu().float(), ref_counts)              # integer counts: bit exact
+    d2 = mf.diagnostics.Histogram2D(axis=(0, 2), edges=(g["edges2x"], g["edges2y"]), bandwidth=(0.5, 0.5),
+                                    kde=False).to(backend)
+    close(d2(x), g["hist2"], 1e-6, 1e-7)
+
+
+def test_forward_list_structure(backend):
+    g = load_golden("ref_forward_list")
+    transforms = []
+    for v in g["V"]:
+        M = torch.eye(6)
+        M[0, :] = v
+        transforms.append(mf.simulate.LinearTransform(M).to(backend))
+    diag = mf.diagnostics.Histogram1D(edges=g["edges"], bandwidth=0.5, axis=0).to(backend)
+    preds = mf.simulate.forward(g["x"].to(backend), transforms, [[diag] for _ in transforms])
+    assert len(preds) == 25 and all(len(p) == 1 for p in preds)
+    close(torch.stack([p[0] for p in preds]), g["preds"], 2e-5, 1e-6)
+
+
+def test_losses_vs_reference(backend):
+    g = load_golden("ref_losses")
+    for suffix in ("", "2"):
+        pred, targ = g["pred" + suffix].to(backend), g["targ" + suffix].to(backend)
+        close(mf.loss.kl_divergence(pred, targ), g["kl" + suffix], 1e-5, 1e-7)
+        close(mf.loss.mean_absolute_error(pred, targ), g["mae" + suffix], 1e-5, 1e-7)
+        close(mf.loss.mean_square_error(pred, targ), g["mse" + suffix], 1e-5, 1e-7)
+    pred = g["pred"].to(backend).clone().requires_grad_(True)
+    mf.loss.kl_divergence(pred, g["targ"].to(backend)).backward()
+    expect = -g["targ"] / (g["pred"] + 1e-12) / 64
+    close(pred.grad, expect, 1e-5, 1e-8)
+
+
+def test_entropy_vs_reference(backend):
+    g = load_golden("ref_entropy_mc")
+    x, lp = g["x"].to(backend), g["log_prob"].to(backend)
+    for s in (1.0, 3.0):
+        est = mf.entropy.MonteCarloEntropyEstimator(prior=mf.prior.Gaussian(6, s))
+        close(est(x, lp), g[f"H_scale{s}"], 1e-5, 1e-6)
+        close(mf.prior.Gaussian(6, s).log_prob(x), g[f"prior_logp_scale{s}"], 1e-5, 1e-5)
+    close(mf.entropy.MonteCarloEntropyEstimator(prior=None)(x, lp), g["H_noprior"], 1e-5, 1e-6)
+
+
+def _loss_case(backend, g, transforms, diagnostics, ndim):
+    meas = [[m.to(backend)] for m in g["measurements"]]
+    for mu in (0, 500):
+        x = g["x"].to(backend).clone().requires_grad_(True)
+        lp = g["log_prob"].to(backend).clone().requires_grad_(True)
+        prior = mf.prior.Gaussian(ndim, float(g["prior_scale"]))
+        model = mf.MENTFlow(transforms=transforms, diagnostics=diagnostics, measurements=meas,
+                            generator=Injected(x, lp), prior=prior,
+                            entropy_estimator=mf.entropy.MonteCarloEntropyEstimator(prior=prior),
+                            discrepancy_function=mf.loss.kl_divergence, penalty_parameter=float(mu))
+        L, H, D = model.loss(x.shape[0])
+        assert isinstance(D, list) and len(D) == len(transforms)
+        L.backward()
+        close(H, g[f"H_mu{mu}"], 1e-5, 1e-6)
+        close(torch.stack(D), g[f"D_mu{mu}"], 2e-4, 1e-7)
+        # L = H + mu * mean(D): D is a cancellation-prone O(1e-2) difference of O(1) sums, good to ~1e-6 absolute
+        # in fp32 on either side, so the absolute tolerance of L carries a mu * 1e-6 term
+        close(L, g[f"L_mu{mu}"], 2e-5, 1e-5 + mu * 1e-6)
+        gmax = float(g[f"gx_mu{mu}"].abs().max())
+        close(x.grad, g[f"gx_mu{mu}"], 1e-3, 2e-5 * gmax)
+        close(lp.grad, g[f"glogp_mu{mu}"], 1e-6, 1e-9)
+        # Trainer-style use of the triple (train.py:165-177)
+        assert not (torch.isinf(L) or torch.isnan(L))
+        float(L), float(H), float(sum(D) / len(D))
+
+
+@pytest.mark.parametrize("P,xmax", [(25, 4.0), (100, 3.5)])
+def test_mentflow_loss_nd_1d(backend, P, xmax):
+    g = load_golden(f"ref_mentflow_loss_1d_P{P}")
+    transforms = [mf.simulate.LinearTransform(M).to(backend) for M in g["matrices"]]
+    diag = mf.diagnostics.Histogram1D(edges=torch.linspace(-xmax, xmax, 65), bandwidth=0.5, axis=0).to(backend)
+    _loss_case(backend, g, transforms, [[diag] for _ in transforms], 6)
+
+
+def test_mentflow_loss_2d_rotations(backend):
+    g = load_golden("ref_mentflow_loss_2d_P7")
+    transforms = [mf.simulate.LinearTransform(M).to(backend) for M in g["matrices"]]
+    diag = mf.diagnostics.Histogram1D(edges=torch.linspace(-3.5, 3.5, 86), bandwidth=0.5, axis=0).to(backend)
+    _loss_case(backend, g, transforms, [[diag] for _ in transforms], 2)
+
+
+def test_mentflow_loss_nd_2d_corner(backend):
+    g = load_golden("ref_mentflow_loss_nd2d_corner15")
+    transforms = [mf.simulate.LinearTransform(M).to(backend) for M in g["matrices"]]
+    e = torch.linspace(-3.5, 3.5, 49)
+    diag = mf.diagnostics.Histogram2D(axis=(0, 2), edges=(e, e), bandwidth=(0.5, 0.5)).to(backend)
+    _loss_case(backend, g, transforms, [[diag] for _ in transforms], 6)
