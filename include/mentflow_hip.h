@@ -28,6 +28,13 @@ const char* mf_last_error(void);
  * infrastructure and is never loaded by the product package.)                                               */
 int mf_is_emulation(void);
 
+/* Per-kernel timing for bench.py: while enabled, every launch of the kernels listed below is bracketed by HIP
+ * events recorded on its own stream.  mf_prof_report(id) synchronises those events and returns the summed
+ * duration (ms) and the number of launches.  ids: 0 flow layer fwd, 1 flow layer bwd, 2 parameter-gradient
+ * contraction (outer_accum), 3 kde1d fwd, 4 kde1d bwd, 5 kde2d fwd, 6 kde2d bwd.                              */
+int mf_prof_enable(int enable);
+int mf_prof_report(int kernel_id, double* total_ms, int64_t* launches);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Generic index gather (weight packing / gradient unpacking for the flow kernels).
  *   dst[j] = idx[j] >= 0 ? src[idx[j]] : 0        (accumulate != 0:  dst[j] += ...)

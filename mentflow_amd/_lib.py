@@ -26,6 +26,8 @@ PROTOTYPES = {
     "mf_abi_version": (_i32, []),
     "mf_last_error": (C.c_char_p, []),
     "mf_is_emulation": (_i32, []),
+    "mf_prof_enable": (_i32, [_i32]),
+    "mf_prof_report": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mf_gather_f32": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _ptr]),
     "mf_flow_image_floats": (_i64, [_i32, _i32]),
     "mf_flow_bwd_scratch_floats": (_i64, [_i64, _i32, _i32]),
@@ -114,3 +116,23 @@ def stream_ptr(t: torch.Tensor):
     if t.device.type == "cuda":
         return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
     return None
+
+
+PROF_KERNELS = {"flow_layer_fwd": 0, "flow_layer_bwd": 1, "outer_accum": 2, "kde1d_fwd": 3, "kde1d_bwd": 4,
+                "kde2d_fwd": 5, "kde2d_bwd": 6}
+
+
+def prof_enable(on: bool) -> None:
+    get_lib().mf_prof_enable(int(on))
+
+
+def prof_report() -> dict:
+    """{kernel: (total_ms, launches)} of the launches recorded since prof_enable(True)."""
+    lib = get_lib()
+    out = {}
+    for name, kid in PROF_KERNELS.items():
+        ms, cnt = C.c_double(0.0), C.c_int64(0)
+        if lib.mf_prof_report(kid, C.byref(ms), C.byref(cnt)) != 0:
+            raise RuntimeError(lib.mf_last_error().decode())
+        out[name] = (ms.value, cnt.value)
+    return out

@@ -36,4 +36,15 @@ constexpr int NUM_CU = 256;   // MI355X: 8 XCDs x 32 CUs
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// Optional per-kernel timing with HIP events recorded on the launch stream (mf_prof_enable / mf_prof_report).
+enum ProfKernel { PK_FLOW_FWD = 0, PK_FLOW_BWD, PK_OUTER_ACCUM, PK_KDE1D_FWD, PK_KDE1D_BWD, PK_KDE2D_FWD, PK_KDE2D_BWD,
+                  PK_COUNT };
+struct ProfScope {
+    int id;
+    void* stream;
+    void* ev0 = nullptr;
+    ProfScope(int id_, void* stream_);
+    ~ProfScope();
+};
+
 }  // namespace mf

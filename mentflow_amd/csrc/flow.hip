@@ -590,6 +590,7 @@ extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layer
     const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, d).total;
 #define X(KK, LL)                                                                                                     \
     if (bins == KK && hidden_layers == LL) {                                                                          \
+        ProfScope prof(PK_FLOW_FWD, stream);                                                                          \
         MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL>), smem);                                                      \
         MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL>), flow_grid(n), FLOW_BLOCK, smem, stream, image, d, x, n, y, logp_in,  \
                   logp_out, init_logp);                                                                               \
@@ -611,6 +612,7 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
     bool launched = false;
 #define X(KK, LL)                                                                                                     \
     if (!launched && bins == KK && hidden_layers == LL) {                                                             \
+        ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
         MF_ALLOW_DYN_SMEM((rqs_layer_bwd_kernel<KK, LL>), smem);                                                      \
         MF_LAUNCH((rqs_layer_bwd_kernel<KK, LL>), flow_grid(n), FLOW_BLOCK, smem, stream, image, d, x, n, gy, glogp,   \
                   gx, scratch);                                                                                       \
@@ -627,6 +629,7 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
     if (G < 1) G = 1;
     if (G > 128) G = 128;
     const int njobs = hidden_layers + d;
+    ProfScope prof(PK_OUTER_ACCUM, stream);
     MF_LAUNCH(outer_accum_kernel, dim3((unsigned)G, njobs), OA_BLOCK, 0, stream, (const float*)scratch, x, n, d,
               hidden_layers, d, gimage);
     return check_launch("mf_flow_rqs_layer_bwd(outer_accum)");

@@ -521,6 +521,7 @@ extern "C" int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* 
     const int ngroups = (P + Pg - 1) / Pg;
     const size_t smem = sizeof(float) * ((size_t)Pg * B + (size_t)Pg * d + B);
     const int G = grid_for(n, KDE_BLOCK * 4, (NUM_CU * 8 + ngroups - 1) / ngroups);
+    ProfScope prof(PK_KDE1D_FWD, stream);
     MF_ALLOW_DYN_SMEM(proj_kde1d_fwd_kernel, smem);
     MF_LAUNCH(proj_kde1d_fwd_kernel, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
               1.0f / sigma, R, S);
@@ -536,6 +537,7 @@ extern "C" int mf_proj_kde1d_bwd(const float* x, int64_t n, int d, const float* 
     const int Pg = (KDE_LDS_FLOATS / B) < P ? (KDE_LDS_FLOATS / B) : P;
     const size_t smem = sizeof(float) * ((size_t)Pg * B + (size_t)Pg * d + B);
     const int64_t G = (n + KDE_BLOCK - 1) / KDE_BLOCK;
+    ProfScope prof(PK_KDE1D_BWD, stream);
     MF_ALLOW_DYN_SMEM(proj_kde1d_bwd_kernel, smem);
     MF_LAUNCH(proj_kde1d_bwd_kernel, dim3((unsigned)G), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
               1.0f / sigma, R, gS, gx, accumulate);
@@ -565,6 +567,7 @@ extern "C" int mf_proj_kde2d_fwd(const float* x, int64_t n, int d, const float* 
     if (n == 0) return 0;
     const int ngroups = (P + Pg - 1) / Pg;
     const int G = grid_for(n, KDE_BLOCK * 4, (NUM_CU * 8 + ngroups - 1) / ngroups);
+    ProfScope prof(PK_KDE2D_FWD, stream);
     MF_ALLOW_DYN_SMEM(proj_kde2d_fwd_kernel, smem);
     MF_LAUNCH(proj_kde2d_fwd_kernel, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V0, V1, P, Pg, coords_x, Bx,
               1.0f / sigma_x, radius_x, coords_y, By, 1.0f / sigma_y, radius_y, S);
@@ -581,6 +584,7 @@ extern "C" int mf_proj_kde2d_bwd(const float* x, int64_t n, int d, const float* 
     if (kde2d_geometry(d, P, Bx, By, radius_x, radius_y, &Pg, &smem, 0)) return 1;
     if (n == 0) return 0;
     const int64_t G = (n + KDE_BLOCK - 1) / KDE_BLOCK;
+    ProfScope prof(PK_KDE2D_BWD, stream);
     MF_ALLOW_DYN_SMEM(proj_kde2d_bwd_kernel, smem);
     MF_LAUNCH(proj_kde2d_bwd_kernel, dim3((unsigned)G), KDE_BLOCK, smem, stream, x, n, d, V0, V1, P, Pg, coords_x, Bx,
               1.0f / sigma_x, radius_x, coords_y, By, 1.0f / sigma_y, radius_y, gS, gx, accumulate);
