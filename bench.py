@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--per-gpu", type=int, default=None, help="particles per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--bwd-chunk", type=int, default=None, help="particles per flow-backward chunk (tuning)")
     args = ap.parse_args()
 
     device = mfdist.init_from_env()
@@ -135,6 +136,8 @@ def main():
     model = prob.model
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0)   # experiments/setup.py:166-170
     torch.manual_seed(1234 + rank)                                           # every rank draws its own particles
+    if args.bwd_chunk:
+        model.generator.spec().bwd_chunk = args.bwd_chunk
     global_batch = per_gpu * world
 
     def step():

@@ -52,17 +52,21 @@ int mf_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, i
  *
  * fwd:  y[n,d] = RQS(x; MLP(x)),   logp_out[n] = (init_logp ? logN(x) : logp_in[n]) - sum_i ladj_i
  *       (logN(x) = -1/2 |x|^2 - d/2 log 2pi: zuko DiagNormal.log_prob of the base draw, first layer only).
+ * order: HOST pointer to the d autoregressive orders of this layer (zuko `order` buffer), or NULL.  With it the kernels
+ *       skip the MFMA k-steps that only multiply masked-out (zero) weights — the image must then hold the hidden
+ *       units sorted by dependency class as packing.py lays them out; NULL = dense products (any image).
  * bwd:  given gy[n,d] = dL/dy and glogp[n] = dL/dlogp, writes gx[n,d] = dL/dx (NULL for the first layer: the
  *       base draw needs no gradient) and accumulates dL/d(image) into gimage (same layout as image; must be
  *       zeroed by the caller before the first chunk).  `scratch` needs mf_flow_bwd_scratch_floats(n,...)
  *       floats.                                                                                             */
 int64_t mf_flow_image_floats(int d, int hidden_layers);
 int64_t mf_flow_bwd_scratch_floats(int64_t n, int d, int hidden_layers);
-int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layers, int bins, const float* x, int64_t n,
-                          float* y, const float* logp_in, float* logp_out, int init_logp, void* stream);
-int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins, const float* x, int64_t n,
-                          const float* gy, const float* glogp, float* gx, float* gimage, float* scratch,
-                          int64_t scratch_floats, void* stream);
+int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
+                          const float* x, int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp,
+                          void* stream);
+int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
+                          const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gimage,
+                          float* scratch, int64_t scratch_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused linear projection + 1-D Gaussian-KDE histogram over P projections.
@@ -74,8 +78,11 @@ int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins
  * Only the 2*radius+1 bins around each projected particle are visited (dropped kernel values are below
  * exp(-(radius+1/2)^2 delta^2 / (2 sigma^2)), 3e-18 for the reference's sigma = delta/2 and radius 4); pass
  * radius >= B for the dense sum.                                                                              */
+/* ws: mf_proj_kde_ws_bytes(P, bins) bytes of scratch (fp64 accumulators of the per-workgroup sums; inside a
+ * workgroup weights are summed as 2^-50 fixed-point integers with 64-bit LDS atomics).                          */
+int64_t mf_proj_kde_ws_bytes(int P, int bins);
 int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* V, int P, const float* coords, int B,
-                      float sigma, int radius, float* S, void* stream);
+                      float sigma, int radius, float* S, void* ws, void* stream);
 /* gx[n,d] (+)= sum_p V_p * sum_k gS[p,k] * K_npk * (-(u_np - c_k)/sigma^2)             */
 int mf_proj_kde1d_bwd(const float* x, int64_t n, int d, const float* V, int P, const float* coords, int B,
                       float sigma, int radius, const float* gS, float* gx, int accumulate, void* stream);
@@ -85,7 +92,7 @@ int mf_proj_kde1d_bwd(const float* x, int64_t n, int d, const float* V, int P, c
  *   S[p,a,b] = sum_n Kx_na Ky_nb   (no 1/N, as the reference)                                                */
 int mf_proj_kde2d_fwd(const float* x, int64_t n, int d, const float* V0, const float* V1, int P,
                       const float* coords_x, int Bx, float sigma_x, int radius_x, const float* coords_y, int By,
-                      float sigma_y, int radius_y, float* S, void* stream);
+                      float sigma_y, int radius_y, float* S, void* ws, void* stream);
 int mf_proj_kde2d_bwd(const float* x, int64_t n, int d, const float* V0, const float* V1, int P,
                       const float* coords_x, int Bx, float sigma_x, int radius_x, const float* coords_y, int By,
                       float sigma_y, int radius_y, const float* gS, float* gx, int accumulate, void* stream);

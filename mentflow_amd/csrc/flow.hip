@@ -25,6 +25,7 @@
 //     and activations as 256-byte rows to an HBM scratch, laid out so that the parameter-gradient contraction over
 //     particles (outer_accum kernel, particles = MFMA k) reads both operands as coalesced fragments.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mf {
 
@@ -56,12 +57,56 @@ __host__ __device__ inline ImageLayout image_layout(int d, int L, int nblk) {
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
+// k-step ranges that skip the all-zero blocks of the autoregressive masks (hidden units are placed sorted by
+// dependency class, two per k-step: mentflow_amd/generate/packing.py).  Computed on the host from (d, order).
+struct Sparsity {
+    int kend_h[2];              // hidden->hidden, output tile rt: k-steps [0, kend_h[rt])
+    int kbeg_ht[2];             // transposed hidden->hidden, output (=input-unit) tile rt: k-steps [kbeg_ht[rt], 32)
+    int kend3[FLOW_DMAX + 1];   // last layer, output block i: k-steps [0, kend3[i])   (0: the block is pure bias)
+    int rt1[FLOW_DMAX + 1];     // transposed last layer, block i: hidden tile 1 receives anything?
+};
+
+static Sparsity make_sparsity(int d, const int32_t* order, int nblk) {
+    Sparsity sp;
+    sp.kend_h[0] = sp.kend_h[1] = 32;
+    sp.kbeg_ht[0] = sp.kbeg_ht[1] = 0;
+    for (int i = 0; i <= FLOW_DMAX; ++i) { sp.kend3[i] = 32; sp.rt1[i] = 1; }
+    if (order == nullptr || d < 2) return sp;                       // dense
+    int cum[FLOW_DMAX + 2];
+    for (int c = 0; c <= d; ++c) {
+        int cnt = 0;
+        for (int u = 0; u < HID; ++u) cnt += (1 + u % (d - 1)) <= c;
+        cum[c] = cnt;
+    }
+    auto class_of = [&](int j) { int c = 1; while (cum[c] <= j) ++c; return c; };
+    for (int rt = 0; rt < 2; ++rt) {
+        sp.kend_h[rt] = (cum[class_of(32 * rt + 31)] + 1) / 2;
+        sp.kbeg_ht[rt] = cum[class_of(32 * rt) - 1] / 2;
+    }
+    if (nblk == d) {                                                  // one output block per feature (RQS)
+        for (int i = 0; i < d; ++i) {
+            sp.kend3[i] = (cum[order[i]] + 1) / 2;
+            sp.rt1[i] = cum[order[i]] > 32;
+        }
+    } else {                                                          // single block holding every feature (affine)
+        sp.kend3[0] = 32;
+        sp.rt1[0] = 1;
+    }
+    return sp;
+}
+
+// The weight image in LDS is constant for the whole kernel, so the compiler hoists the (loop-invariant) bias and
+// weight-fragment loads of every layer out of the particle-tile loop and then spills them (104 VGPRs spilled in the
+// forward kernel).  A compiler-only memory barrier at the top of each tile keeps the loads next to their MFMAs.
+#define MF_NO_HOIST() asm volatile("" ::: "memory")
+
 __device__ __forceinline__ f32x16_t mfma(float a, float b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+template <int BLOCK = FLOW_BLOCK>
 __device__ __forceinline__ void stage_image(float* lds, const float* __restrict__ image, int total) {
-    for (int i = threadIdx.x * 4; i < total; i += FLOW_BLOCK * 4)
+    for (int i = threadIdx.x * 4; i < total; i += BLOCK * 4)
         *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(image + i);
     __syncthreads();
 }
@@ -75,31 +120,36 @@ __device__ __forceinline__ f32x16_t bias_tile(const float* b, int rt, int hh) {
 }
 
 // out[2] = W[64 x 64] * in[2]  (+ bias), weights natural [out][in] with stride WS
+// k-steps [0, kend0) for output tile 0 and [0, kend1) for tile 1 (wave-uniform bounds: masked-out blocks skipped)
 __device__ __forceinline__ void linear64(const float* W, const float* b, const f32x16_t (&in)[2], f32x16_t (&out)[2],
-                                         int col, int hh) {
+                                         int col, int hh, int kend0, int kend1) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         f32x16_t acc = bias_tile(b, rt, hh);
         const float* wrow = W + (32 * rt + col) * WS + 4 * hh;
+        const int kend = rt ? kend1 : kend0;
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
-            acc = mfma(wrow[kk], in[s >> 4][s & 15], acc);
+            if (s < kend) acc = mfma(wrow[kk], in[s >> 4][s & 15], acc);
         }
         out[rt] = acc;
     }
 }
 
 // out[2] += W^T * in[2]   (out rows = input units of W, contraction over W's output units)
-__device__ __forceinline__ void linear64_t(const float* W, const f32x16_t (&in)[2], f32x16_t (&out)[2], int col, int hh) {
+// k-steps [kbeg0, 32) for output tile 0 and [kbeg1, 32) for tile 1
+__device__ __forceinline__ void linear64_t(const float* W, const f32x16_t (&in)[2], f32x16_t (&out)[2], int col, int hh,
+                                           int kbeg0, int kbeg1) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         f32x16_t acc = out[rt];
         const float* wcol = W + 4 * hh * WS + 32 * rt + col;
+        const int kbeg = rt ? kbeg1 : kbeg0;
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
-            acc = mfma(wcol[kk * WS], in[s >> 4][s & 15], acc);
+            if (s >= kbeg) acc = mfma(wcol[kk * WS], in[s >> 4][s & 15], acc);
         }
         out[rt] = acc;
     }
@@ -273,9 +323,9 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
 
 // A[in rows of tile] fragment of one output block (64 padded rows) of the last linear layer
 __device__ __forceinline__ void block_linear(const float* W, const float* b, const f32x16_t (&in)[2], float (&v)[32],
-                                             int col, int hh) {
+                                             int col, int hh, int kend) {
     f32x16_t phi[2];
-    linear64(W, b, in, phi, col, hh);
+    linear64(W, b, in, phi, col, hh, kend, kend);
 #pragma unroll
     for (int m = 0; m < 32; ++m) v[m] = phi[m >> 4][m & 15];
 }
@@ -287,18 +337,20 @@ __device__ __forceinline__ float base_log_prob(const float* xp, int d) {
 }
 
 // =========================================================================================== forward, RQS
-template <int K, int L>
-__global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_fwd_kernel(const float* __restrict__ image, int d,
+template <int K, int L, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __restrict__ image, int d,
                                                                    const float* __restrict__ x, int64_t n,
                                                                    float* __restrict__ y,
                                                                    const float* __restrict__ logp_in,
-                                                                   float* __restrict__ logp_out, int init_logp) {
+                                                                   float* __restrict__ logp_out, int init_logp,
+                                                                   Sparsity sp) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
-    stage_image(lds, image, g.total);
+    stage_image<BLOCK>(lds, image, g.total);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
     const int64_t ntiles = (n + 31) / 32;
-    for (int64_t tile = (int64_t)blockIdx.x * FLOW_WAVES + wid; tile < ntiles; tile += (int64_t)gridDim.x * FLOW_WAVES) {
+    for (int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (BLOCK / 64)) {
+        MF_NO_HOIST();
         const int64_t p = tile * 32 + col;
         const bool valid = p < n;
         const float* xp = x + (valid ? p : n - 1) * d;
@@ -311,15 +363,16 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_fwd_kernel(const float* 
         for (int l = 1; l < L; ++l) {
             f32x16_t t[2];
             const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
-            linear64(W, W + HID * WS, h, t, col, hh);
+            linear64(W, W + HID * WS, h, t, col, hh, sp.kend_h[0], sp.kend_h[1]);
             relu2(t);
             h[0] = t[0];
             h[1] = t[1];
         }
         float ladj = 0.0f;
+#pragma unroll 1
         for (int i = 0; i < d; ++i) {
             float v[32], gdummy[32];
-            block_linear(lds + g.offW3 + i * HID * WS, lds + g.offB3 + i * HID, h, v, col, hh);
+            block_linear(lds + g.offW3 + i * HID * WS, lds + g.offB3 + i * HID, h, v, col, hh, sp.kend3[i]);
             float yi, li, gxd;
             rqs_apply<K, false>(v, xp[i], hh, yi, li, 0.0f, 0.0f, gdummy, gxd);
             ladj += li;
@@ -332,18 +385,25 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_fwd_kernel(const float* 
     }
 }
 
-// scratch rows: 64 floats per particle, column = hh*32 + slot  (slot m <-> accumulator (m>>4, m&15))
+// scratch rows: 64 floats per particle; column c = 32*rt + 16*hh + r holds accumulator register r of row tile rt of
+// lane half hh, i.e. MFMA row 32*rt + rowmap(r, hh): memory tile (c >> 5) == MFMA row tile, so the parameter-gradient
+// contraction can skip whole 32-column tiles that the autoregressive masks zero out.
 __device__ __forceinline__ void store_row(float* __restrict__ dst, int64_t p, int hh, const float (&v)[32]) {
-    float4* q = reinterpret_cast<float4*>(dst + p * 64 + hh * 32);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    for (int rt = 0; rt < 2; ++rt) {
+        float4* q = reinterpret_cast<float4*>(dst + p * 64 + 32 * rt + 16 * hh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            q[j] = make_float4(v[16 * rt + 4 * j], v[16 * rt + 4 * j + 1], v[16 * rt + 4 * j + 2], v[16 * rt + 4 * j + 3]);
+    }
 }
 __device__ __forceinline__ void store_row(float* __restrict__ dst, int64_t p, int hh, const f32x16_t (&a)[2]) {
-    float4* q = reinterpret_cast<float4*>(dst + p * 64 + hh * 32);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        q[j] = make_float4(a[j >> 2][4 * (j & 3)], a[j >> 2][4 * (j & 3) + 1], a[j >> 2][4 * (j & 3) + 2],
-                           a[j >> 2][4 * (j & 3) + 3]);
+    for (int rt = 0; rt < 2; ++rt) {
+        float4* q = reinterpret_cast<float4*>(dst + p * 64 + 32 * rt + 16 * hh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = make_float4(a[rt][4 * j], a[rt][4 * j + 1], a[rt][4 * j + 2], a[rt][4 * j + 3]);
+    }
 }
 
 // =========================================================================================== backward, RQS
@@ -353,7 +413,8 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
                                                                    const float* __restrict__ x, int64_t n,
                                                                    const float* __restrict__ gy,
                                                                    const float* __restrict__ glogp,
-                                                                   float* __restrict__ gx, float* __restrict__ scratch) {
+                                                                   float* __restrict__ gx, float* __restrict__ scratch,
+                                                                   Sparsity sp) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
     stage_image(lds, image, g.total);
@@ -364,6 +425,7 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
     float* GPRE = ACT + (int64_t)L * npad * 64;
     float* GPHI = GPRE + (int64_t)L * npad * 64;
     for (int64_t tile = (int64_t)blockIdx.x * FLOW_WAVES + wid; tile < ntiles; tile += (int64_t)gridDim.x * FLOW_WAVES) {
+        MF_NO_HOIST();
         const int64_t p = tile * 32 + col;
         const bool valid = p < n;
         const int64_t pc = valid ? p : n - 1;
@@ -378,7 +440,7 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
 #pragma unroll
         for (int l = 1; l < L; ++l) {
             const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
-            linear64(W, W + HID * WS, h[l - 1], h[l], col, hh);
+            linear64(W, W + HID * WS, h[l - 1], h[l], col, hh, sp.kend_h[0], sp.kend_h[1]);
             relu2(h[l]);
             store_row(ACT + (int64_t)l * npad * 64, p, hh, h[l]);
         }
@@ -392,10 +454,11 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
             gacc[r] = 0.0f;
         }
         const float gl = valid ? -glogp[pc] : 0.0f;
+#pragma unroll 1
         for (int i = 0; i < d; ++i) {
             float v[32], gv[32];
             const float* W3 = lds + g.offW3 + i * HID * WS;
-            block_linear(W3, lds + g.offB3 + i * HID, h[L - 1], v, col, hh);
+            block_linear(W3, lds + g.offB3 + i * HID, h[L - 1], v, col, hh, sp.kend3[i]);
             const float gyi = valid ? gy[pc * d + i] : 0.0f;
             float yi, li, gxd;
             rqs_apply<K, true>(v, xp[i], hh, yi, li, gyi, gl, gv, gxd);
@@ -403,17 +466,21 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
 #pragma unroll
             for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
             store_row(GPHI + (int64_t)i * npad * 64, p, hh, gv);
-            // gh += W3_i^T gphi   (contraction over the 64 padded output rows = slots of both halves)
+            // gh += W3_i^T gphi   (contraction over the 64 padded output rows = slots of both halves); hidden tile 1
+            // only receives something if block i sees more than 32 hidden units, nothing at all for a pure-bias block
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                f32x16_t acc = gh[rt];
-                const float* wcol = W3 + 4 * hh * WS + 32 * rt + col;
+                const bool need = rt ? (sp.rt1[i] != 0) : (sp.kend3[i] > 0);
+                if (need) {
+                    f32x16_t acc = gh[rt];
+                    const float* wcol = W3 + 4 * hh * WS + 32 * rt + col;
 #pragma unroll
-                for (int s = 0; s < 32; ++s) {
-                    const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
-                    acc = mfma(wcol[kk * WS], gv[s], acc);
+                    for (int s = 0; s < 32; ++s) {
+                        const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
+                        acc = mfma(wcol[kk * WS], gv[s], acc);
+                    }
+                    gh[rt] = acc;
                 }
-                gh[rt] = acc;
             }
         }
         // ---- trunk backward
@@ -430,7 +497,7 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
                 t[0][r] = 0.0f;
                 t[1][r] = 0.0f;
             }
-            linear64_t(lds + g.offWh + (l - 1) * (HID * WS + HID), gh, t, col, hh);
+            linear64_t(lds + g.offWh + (l - 1) * (HID * WS + HID), gh, t, col, hh, sp.kbeg_ht[0], sp.kbeg_ht[1]);
             gh[0] = t[0];
             gh[1] = t[1];
         }
@@ -464,7 +531,7 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
 constexpr int OA_BLOCK = 256;
 __global__ __launch_bounds__(OA_BLOCK) void outer_accum_kernel(const float* __restrict__ scratch,
                                                                const float* __restrict__ x, int64_t n, int d, int L,
-                                                               int nblk, float* __restrict__ gimage) {
+                                                               int nblk, float* __restrict__ gimage, Sparsity sp) {
     __shared__ float tileC[64 * 64];
     __shared__ float tileB[64];
     const ImageLayout g = image_layout(d, L, nblk);
@@ -477,9 +544,11 @@ __global__ __launch_bounds__(OA_BLOCK) void outer_accum_kernel(const float* __re
     const float* A;
     const float* B = nullptr;
     int offW, offB, strideW;
+    bool need_b0 = true, need_b1 = true;       // which 32-column tiles of B can be non-zero
     if (job == 0) {
         A = GPRE;
         offW = g.offW0; offB = g.offB0; strideW = g.S0;
+        need_b1 = false;
     } else if (job < L) {
         A = GPRE + (int64_t)job * npad * 64;
         B = ACT + (int64_t)(job - 1) * npad * 64;
@@ -489,6 +558,8 @@ __global__ __launch_bounds__(OA_BLOCK) void outer_accum_kernel(const float* __re
         A = GPHI + (int64_t)i * npad * 64;
         B = ACT + (int64_t)(L - 1) * npad * 64;
         offW = g.offW3 + i * HID * WS; offB = g.offB3 + i * HID; strideW = WS;
+        need_b0 = sp.kend3[i] > 0;
+        need_b1 = sp.rt1[i] != 0;
     }
     for (int i = threadIdx.x; i < 64 * 64; i += OA_BLOCK) tileC[i] = 0.0f;
     if (threadIdx.x < 64) tileB[threadIdx.x] = 0.0f;
@@ -519,32 +590,32 @@ __global__ __launch_bounds__(OA_BLOCK) void outer_accum_kernel(const float* __re
         }
         bsum0 += a0;
         bsum1 += a1;
-        acc[0][0] = mfma(a0, b0, acc[0][0]);
-        acc[1][0] = mfma(a1, b0, acc[1][0]);
-        if (job != 0) {
+        if (need_b0) {
+            acc[0][0] = mfma(a0, b0, acc[0][0]);
+            acc[1][0] = mfma(a1, b0, acc[1][0]);
+        }
+        if (need_b1) {
             acc[0][1] = mfma(a0, b1, acc[0][1]);
             acc[1][1] = mfma(a1, b1, acc[1][1]);
         }
     }
-    // memory column c = hhc*32 + m  <->  physical row rho = 32*(m>>4) + rowmap(m&15, hhc)
-    const int mB = col;   // b_mem = 32*tb + col -> hhc = tb, m = col
+    // memory column c = 32*rt + 16*hc + r  <->  physical (image) row rho = 32*rt + rowmap(r, hc)
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
-            const int rhoB = (job == 0) ? col : (32 * (mB >> 4) + rowmap(mB & 15, tb));
+            const int rhoB = (job == 0) ? col : (32 * tb + rowmap(col & 15, col >> 4));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int mA = rowmap(r, hh);                       // a_mem = 32*ta + mA -> hhc = ta, m = mA
-                const int rhoA = 32 * (mA >> 4) + rowmap(mA & 15, ta);
-                if (job != 0 || tb == 0) atomicAdd(&tileC[rhoA * 64 + rhoB], acc[ta][tb][r]);
+                const int wA = rowmap(r, hh);                       // C row within the tile = memory column of A
+                const int rhoA = 32 * ta + rowmap(wA & 15, wA >> 4);
+                if (tb ? need_b1 : need_b0) atomicAdd(&tileC[rhoA * 64 + rhoB], acc[ta][tb][r]);
             }
         }
     {
-        const int rho0 = 32 * (col >> 4) + rowmap(col & 15, 0);
-        const int rho1 = 32 * (col >> 4) + rowmap(col & 15, 1);
-        atomicAdd(&tileB[rho0], bsum0);
-        atomicAdd(&tileB[rho1], bsum1);
+        const int rho = rowmap(col & 15, col >> 4);
+        atomicAdd(&tileB[rho], bsum0);
+        atomicAdd(&tileB[32 + rho], bsum1);
     }
     __syncthreads();
     const int ncolsB = (job == 0) ? d : 64;
@@ -562,9 +633,9 @@ static int flow_check(int d, int L, int64_t n) {
     return 0;
 }
 
-static int flow_grid(int64_t n) {
+static int flow_grid(int64_t n, int waves = FLOW_WAVES) {
     const int64_t ntiles = (n + 31) / 32;
-    int64_t g = (ntiles + FLOW_WAVES - 1) / FLOW_WAVES;
+    int64_t g = (ntiles + waves - 1) / waves;
     if (g > NUM_CU) g = NUM_CU;
     if (g < 1) g = 1;
     return (int)g;
@@ -583,17 +654,30 @@ extern "C" int64_t mf_flow_bwd_scratch_floats(int64_t n, int d, int hidden_layer
 
 #define MF_RQS_CASES(X) X(20, 3) X(20, 2) X(8, 3) X(8, 2)
 
-extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layers, int bins, const float* x, int64_t n,
-                                      float* y, const float* logp_in, float* logp_out, int init_logp, void* stream) {
+extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
+                                      const float* x, int64_t n, float* y, const float* logp_in, float* logp_out,
+                                      int init_logp, void* stream) {
     if (flow_check(d, hidden_layers, n)) return 1;
     if (n == 0) return 0;
+    const Sparsity sp = make_sparsity(d, order, d);
     const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, d).total;
+    // 1024-thread workgroups (4 waves per SIMD at <= 128 VGPRs) hide LDS and spline latency better than 512
+    static const int fwd_block = [] {
+        const char* e = getenv("MENTFLOW_FWD_BLOCK");
+        return (e && atoi(e) == 512) ? 512 : 1024;
+    }();
 #define X(KK, LL)                                                                                                     \
     if (bins == KK && hidden_layers == LL) {                                                                          \
         ProfScope prof(PK_FLOW_FWD, stream);                                                                          \
-        MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL>), smem);                                                      \
-        MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL>), flow_grid(n), FLOW_BLOCK, smem, stream, image, d, x, n, y, logp_in,  \
-                  logp_out, init_logp);                                                                               \
+        if (fwd_block == 1024) {                                                                                      \
+            MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL, 1024>), smem);                                            \
+            MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL, 1024>), flow_grid(n, 16), 1024, smem, stream, image, d, x, n, y,   \
+                      logp_in, logp_out, init_logp, sp);                                                              \
+        } else {                                                                                                      \
+            MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL, 512>), smem);                                             \
+            MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL, 512>), flow_grid(n, 8), 512, smem, stream, image, d, x, n, y,      \
+                      logp_in, logp_out, init_logp, sp);                                                              \
+        }                                                                                                             \
         return check_launch("mf_flow_rqs_layer_fwd");                                                                 \
     }
     MF_RQS_CASES(X)
@@ -602,11 +686,12 @@ extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layer
                 hidden_layers);
 }
 
-extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins, const float* x, int64_t n,
-                                      const float* gy, const float* glogp, float* gx, float* gimage, float* scratch,
-                                      int64_t scratch_floats, void* stream) {
+extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
+                                      const float* x, int64_t n, const float* gy, const float* glogp, float* gx,
+                                      float* gimage, float* scratch, int64_t scratch_floats, void* stream) {
     if (flow_check(d, hidden_layers, n)) return 1;
     if (n == 0) return 0;
+    const Sparsity sp = make_sparsity(d, order, d);
     if (scratch_floats < mf_flow_bwd_scratch_floats(n, d, hidden_layers)) return fail("scratch too small");
     const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, d).total;
     bool launched = false;
@@ -615,7 +700,7 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
         ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
         MF_ALLOW_DYN_SMEM((rqs_layer_bwd_kernel<KK, LL>), smem);                                                      \
         MF_LAUNCH((rqs_layer_bwd_kernel<KK, LL>), flow_grid(n), FLOW_BLOCK, smem, stream, image, d, x, n, gy, glogp,   \
-                  gx, scratch);                                                                                       \
+                  gx, scratch, sp);                                                                                   \
         launched = true;                                                                                              \
     }
     MF_RQS_CASES(X)
@@ -631,6 +716,6 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
     const int njobs = hidden_layers + d;
     ProfScope prof(PK_OUTER_ACCUM, stream);
     MF_LAUNCH(outer_accum_kernel, dim3((unsigned)G, njobs), OA_BLOCK, 0, stream, (const float*)scratch, x, n, d,
-              hidden_layers, d, gimage);
+              hidden_layers, d, gimage, sp);
     return check_launch("mf_flow_rqs_layer_bwd(outer_accum)");
 }

@@ -12,8 +12,13 @@
 // Design (HBM-bound byte work; no MFMA here): one lane per particle, particle rows read once (coalesced,
 // d floats per lane), projection vectors / bin centres / the histogram image of a group of projections live in
 // LDS; every particle touches only the 2R+1 bins whose Gaussian weight is above fp32 resolution (sigma = bw*delta,
-// R = ceil(9 bw - 1/2): dropped weights < 3e-18), accumulated with LDS float atomics and flushed with one global
-// float atomic per bin per workgroup.
+// R = ceil(9 bw - 1/2): dropped weights < 3e-18).
+// Accumulation inside a workgroup is FIXED POINT: each weight (<= 1) is converted to a 2^-50 integer and added with
+// 64-bit integer LDS atomics (order independent, 8.9e-16 quantum: far-tail bins, whose log enters the KL
+// discrepancy, keep their relative accuracy); the
+// per-workgroup sums are flushed with one fp64 global atomic per bin and rounded to fp32 once at the end.
+// Measured on MI355X (tools/ubench_lds_atomics.hip): ds_add_f32 sustains 0.33 lane-ops/clk/CU, ds_add_u64 2.7 — the
+// float LDS atomic is 8x slower.
 #include "common.h"
 
 namespace mf {
@@ -44,18 +49,36 @@ __device__ __forceinline__ int centre_bin(float u, float c0, float inv_delta, in
 }
 
 // ------------------------------------------------------------------------------------------------ 1-D forward
-// grid (G, ngroups); LDS: [Pg*B] image | [Pg*d] V | [B] coords
+typedef unsigned long long u64;
+constexpr double KDE_FIX_INV = 1.0 / 1125899906842624.0; // 2^-50: fixed-point quantum of the LDS histogram image
+constexpr int KDE_MAX_PER_WG = 4096;                     // particles per workgroup: 2^12 * 2^50 < 2^63, no overflow
+constexpr float KDE_EXP2_SCALE = 0.7213475204444817f;    // log2(e) / 2:  exp(-r^2/2) = exp2(-KDE_EXP2_SCALE r^2)
+
+__device__ __forceinline__ float gauss_weight(float r) { return __builtin_amdgcn_exp2f(-KDE_EXP2_SCALE * r * r); }
+
+// w in [0, 1] -> round-down 2^-50 fixed point (exact split: high 18 bits and low 32 bits of w * 2^50)
+__device__ __forceinline__ u64 to_fix(float w) {
+    const float t = w * 262144.0f;
+    const unsigned hi = (unsigned)t;
+    const unsigned lo = (unsigned)((t - (float)hi) * 4294967296.0f);
+    return ((u64)hi << 32) | (u64)lo;
+}
+
+// grid (G, ngroups); LDS: [Pg*B] u64 image | [Pg*ds] V (row stride ds = d|1, odd) | [B] coords
+template <int RT>   // RT > 0: compile-time window radius (unrolled);  RT == 0: runtime radius
 __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_fwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V, int P, int Pg,
-    const float* __restrict__ coords, int B, float inv_sigma, int R, float* __restrict__ S) {
-    MF_DYN_SMEM(float, lds);
-    float* img = lds;
-    float* Vl = img + Pg * B;
-    float* cl = Vl + Pg * d;
+    const float* __restrict__ coords, int B, float inv_sigma, int Rrt, double* __restrict__ Sacc) {
+    MF_DYN_SMEM(u64, lds);
+    u64* img = lds;
+    const int ds = d | 1;
+    float* Vl = reinterpret_cast<float*>(img + Pg * B);
+    float* cl = Vl + Pg * ds;
     const int p_begin = blockIdx.y * Pg;
     const int np = min(Pg, P - p_begin);
-    for (int i = threadIdx.x; i < np * B; i += KDE_BLOCK) img[i] = 0.0f;
-    for (int i = threadIdx.x; i < np * d; i += KDE_BLOCK) Vl[i] = V[p_begin * d + i];
+    const int R = RT > 0 ? RT : Rrt;
+    for (int i = threadIdx.x; i < np * B; i += KDE_BLOCK) img[i] = 0;
+    for (int i = threadIdx.x; i < np * d; i += KDE_BLOCK) Vl[(i / d) * ds + (i % d)] = V[p_begin * d + i];
     for (int i = threadIdx.x; i < B; i += KDE_BLOCK) cl[i] = coords[i];
     __syncthreads();
     const float c0 = cl[0];
@@ -63,23 +86,45 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_fwd_kernel(
     for (int64_t p = (int64_t)blockIdx.x * KDE_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * KDE_BLOCK) {
         float xv[KDE_DMAX];
         load_row(x, p, d, xv);
-        for (int q = 0; q < np; ++q) {
-            const float u = project(xv, Vl + q * d, d);
+        // every lane starts at a different projection: the 64 lanes of a wave then add into different rows of the
+        // image instead of piling onto the few populated bins of one projection
+        int q = (int)(threadIdx.x % (unsigned)np);
+        for (int it = 0; it < np; ++it) {
+            const float u = project(xv, Vl + q * ds, d);
             const int kc = centre_bin(u, c0, inv_delta, B, R);
-            for (int j = -R; j <= R; ++j) {
-                const int k = kc + j;
-                if (k >= 0 && k < B) {
-                    const float r = (u - cl[k]) * inv_sigma;
-                    atomicAdd(&img[q * B + k], expf(-0.5f * r * r));
+            u64* row = img + q * B;
+            if (RT > 0) {
+#pragma unroll
+                for (int j = -RT; j <= RT; ++j) {
+                    const int k = kc + j;
+                    if (k >= 0 && k < B) {
+                        const float w = gauss_weight((u - cl[k]) * inv_sigma);
+                        atomicAdd(&row[k], to_fix(w));
+                    }
+                }
+            } else {
+                for (int j = -R; j <= R; ++j) {
+                    const int k = kc + j;
+                    if (k >= 0 && k < B) {
+                        const float w = gauss_weight((u - cl[k]) * inv_sigma);
+                        atomicAdd(&row[k], to_fix(w));
+                    }
                 }
             }
+            q = (q + 1 == np) ? 0 : q + 1;
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < np * B; i += KDE_BLOCK) {
-        const float v = img[i];
-        if (v != 0.0f) atomicAdd(&S[(int64_t)p_begin * B + i], v);
+        const u64 v = img[i];
+        if (v != 0) atomicAdd(&Sacc[(int64_t)p_begin * B + i], (double)v * KDE_FIX_INV);
     }
+}
+
+__global__ __launch_bounds__(KDE_BLOCK) void acc_to_float_kernel(const double* __restrict__ Sacc, float* __restrict__ S,
+                                                                  int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * KDE_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * KDE_BLOCK)
+        S[i] = (float)Sacc[i];
 }
 
 // ------------------------------------------------------------------------------------------------ 1-D backward
@@ -116,7 +161,7 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
                 const int k = kc + j;
                 if (k >= 0 && k < B) {
                     const float r = (u - cl[k]) * inv_sigma;
-                    du = fmaf(img[q * B + k] * expf(-0.5f * r * r), -r * inv_sigma, du);
+                    du = fmaf(img[q * B + k] * gauss_weight(r), -r * inv_sigma, du);
                 }
             }
 #pragma unroll
@@ -132,24 +177,25 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ 2-D forward
-// grid (G, ngroups); LDS: [Pg*Bx*By] image | [Pg*d] V0 | [Pg*d] V1 | [Bx] cx | [By] cy
+// grid (G, ngroups); LDS: [Pg*Bx*By] u64 image | [Pg*ds] V0 | [Pg*ds] V1 | [Bx] cx | [By] cy
 __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_fwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V0, const float* __restrict__ V1, int P,
     int Pg, const float* __restrict__ coords_x, int Bx, float inv_sx, int Rx, const float* __restrict__ coords_y,
-    int By, float inv_sy, int Ry, float* __restrict__ S) {
-    MF_DYN_SMEM(float, lds);
+    int By, float inv_sy, int Ry, double* __restrict__ Sacc) {
+    MF_DYN_SMEM(u64, lds);
     const int BB = Bx * By;
-    float* img = lds;
-    float* V0l = img + Pg * BB;
-    float* V1l = V0l + Pg * d;
-    float* cxl = V1l + Pg * d;
+    const int ds = d | 1;
+    u64* img = lds;
+    float* V0l = reinterpret_cast<float*>(img + Pg * BB);
+    float* V1l = V0l + Pg * ds;
+    float* cxl = V1l + Pg * ds;
     float* cyl = cxl + Bx;
     const int p_begin = blockIdx.y * Pg;
     const int np = min(Pg, P - p_begin);
-    for (int i = threadIdx.x; i < np * BB; i += KDE_BLOCK) img[i] = 0.0f;
+    for (int i = threadIdx.x; i < np * BB; i += KDE_BLOCK) img[i] = 0;
     for (int i = threadIdx.x; i < np * d; i += KDE_BLOCK) {
-        V0l[i] = V0[p_begin * d + i];
-        V1l[i] = V1[p_begin * d + i];
+        V0l[(i / d) * ds + (i % d)] = V0[p_begin * d + i];
+        V1l[(i / d) * ds + (i % d)] = V1[p_begin * d + i];
     }
     for (int i = threadIdx.x; i < Bx; i += KDE_BLOCK) cxl[i] = coords_x[i];
     for (int i = threadIdx.x; i < By; i += KDE_BLOCK) cyl[i] = coords_y[i];
@@ -160,8 +206,8 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_fwd_kernel(
         float xv[KDE_DMAX];
         load_row(x, p, d, xv);
         for (int q = 0; q < np; ++q) {
-            const float u0 = project(xv, V0l + q * d, d);
-            const float u1 = project(xv, V1l + q * d, d);
+            const float u0 = project(xv, V0l + q * ds, d);
+            const float u1 = project(xv, V1l + q * ds, d);
             const int ka = centre_bin(u0, cx0, inv_dx, Bx, Rx);
             const int kb = centre_bin(u1, cy0, inv_dy, By, Ry);
             float wy[2 * KDE_RMAX2D + 1];
@@ -169,30 +215,26 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_fwd_kernel(
             for (int j = 0; j < 2 * KDE_RMAX2D + 1; ++j) {
                 const int b = kb - Ry + j;
                 float w = 0.0f;
-                if (j <= 2 * Ry && b >= 0 && b < By) {
-                    const float r = (u1 - cyl[b]) * inv_sy;
-                    w = expf(-0.5f * r * r);
-                }
+                if (j <= 2 * Ry && b >= 0 && b < By) w = gauss_weight((u1 - cyl[b]) * inv_sy);
                 wy[j] = w;
             }
             for (int i = 0; i <= 2 * Rx; ++i) {
                 const int a = ka - Rx + i;
                 if (a < 0 || a >= Bx) continue;
-                const float r = (u0 - cxl[a]) * inv_sx;
-                const float wx = expf(-0.5f * r * r);
-                float* row = img + q * BB + a * By;
+                const float wx = gauss_weight((u0 - cxl[a]) * inv_sx);
+                u64* row = img + q * BB + a * By;
 #pragma unroll
                 for (int j = 0; j < 2 * KDE_RMAX2D + 1; ++j) {
                     const int b = kb - Ry + j;
-                    if (j <= 2 * Ry && b >= 0 && b < By) atomicAdd(&row[b], wx * wy[j]);
+                    if (j <= 2 * Ry && b >= 0 && b < By) atomicAdd(&row[b], to_fix(wx * wy[j]));
                 }
             }
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < np * BB; i += KDE_BLOCK) {
-        const float v = img[i];
-        if (v != 0.0f) atomicAdd(&S[(int64_t)p_begin * BB + i], v);
+        const u64 v = img[i];
+        if (v != 0) atomicAdd(&Sacc[(int64_t)p_begin * BB + i], (double)v * KDE_FIX_INV);
     }
 }
 
@@ -240,7 +282,7 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
                 float w = 0.0f, dw = 0.0f;
                 if (j <= 2 * Ry && b >= 0 && b < By) {
                     const float r = (u1 - cyl[b]) * inv_sy;
-                    w = expf(-0.5f * r * r);
+                    w = gauss_weight(r);
                     dw = -r * inv_sy * w;
                 }
                 wy[j] = w;
@@ -251,7 +293,7 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
                 const int a = ka - Rx + i;
                 if (a < 0 || a >= Bx) continue;
                 const float r = (u0 - cxl[a]) * inv_sx;
-                const float wx = expf(-0.5f * r * r);
+                const float wx = gauss_weight(r);
                 const float dwx = -r * inv_sx * wx;
                 const float* row = img + q * BB + a * By;
                 float sa = 0.0f, sb = 0.0f;
@@ -510,22 +552,41 @@ static int kde_check(int64_t n, int d, int P, int B) {
     return 0;
 }
 
+extern "C" int64_t mf_proj_kde_ws_bytes(int P, int bins) { return (int64_t)P * bins * (int64_t)sizeof(double); }
+
+static int fix_finish(const double* Sacc, float* S, int64_t total, void* stream) {
+    MF_LAUNCH(acc_to_float_kernel, grid_for(total, KDE_BLOCK, 1024), KDE_BLOCK, 0, stream, Sacc, S, total);
+    return check_launch("acc_to_float");
+}
+
 extern "C" int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* V, int P, const float* coords, int B,
-                                  float sigma, int radius, float* S, void* stream) {
+                                  float sigma, int radius, float* S, void* ws, void* stream) {
     if (kde_check(n, d, P, B)) return 1;
-    if (B > KDE_LDS_FLOATS) return fail("too many bins for the LDS image (%d)", B);
-    if (hipMemsetAsync(S, 0, sizeof(float) * (size_t)P * B, (hipStream_t)stream) != hipSuccess) return fail("memset S");
-    if (n == 0) return 0;
-    const int R = radius < 0 ? 0 : (radius > B ? B : radius);
-    const int Pg = (KDE_LDS_FLOATS / B) < P ? (KDE_LDS_FLOATS / B) : P;
-    const int ngroups = (P + Pg - 1) / Pg;
-    const size_t smem = sizeof(float) * ((size_t)Pg * B + (size_t)Pg * d + B);
-    const int G = grid_for(n, KDE_BLOCK * 4, (NUM_CU * 8 + ngroups - 1) / ngroups);
-    ProfScope prof(PK_KDE1D_FWD, stream);
-    MF_ALLOW_DYN_SMEM(proj_kde1d_fwd_kernel, smem);
-    MF_LAUNCH(proj_kde1d_fwd_kernel, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
-              1.0f / sigma, R, S);
-    return check_launch("mf_proj_kde1d_fwd");
+    const int budget = KDE_LDS_FLOATS / 2;            // 64-bit bins
+    if (B > budget) return fail("too many bins for the LDS image (%d)", B);
+    double* Sfix = reinterpret_cast<double*>(ws);
+    if (hipMemsetAsync(Sfix, 0, sizeof(double) * (size_t)P * B, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
+    if (n > 0) {
+        const int R = radius < 0 ? 0 : (radius > B ? B : radius);
+        const int Pg = (budget / B) < P ? (budget / B) : P;
+        const int ngroups = (P + Pg - 1) / Pg;
+        const int ds = d | 1;
+        const size_t smem = sizeof(u64) * (size_t)Pg * B + sizeof(float) * ((size_t)Pg * ds + B);
+        int G = grid_for(n, KDE_BLOCK * 4, (NUM_CU * 8 + ngroups - 1) / ngroups);
+        if ((n + G - 1) / G > KDE_MAX_PER_WG) G = (int)((n + KDE_MAX_PER_WG - 1) / KDE_MAX_PER_WG);
+        ProfScope prof(PK_KDE1D_FWD, stream);
+        if (R == 4) {
+            MF_ALLOW_DYN_SMEM(proj_kde1d_fwd_kernel<4>, smem);
+            MF_LAUNCH(proj_kde1d_fwd_kernel<4>, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
+                      1.0f / sigma, R, Sfix);
+        } else {
+            MF_ALLOW_DYN_SMEM(proj_kde1d_fwd_kernel<0>, smem);
+            MF_LAUNCH(proj_kde1d_fwd_kernel<0>, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
+                      1.0f / sigma, R, Sfix);
+        }
+        if (check_launch("mf_proj_kde1d_fwd")) return 1;
+    }
+    return fix_finish(Sfix, S, (int64_t)P * B, stream);
 }
 
 extern "C" int mf_proj_kde1d_bwd(const float* x, int64_t n, int d, const float* V, int P, const float* coords, int B,
@@ -558,20 +619,30 @@ static int kde2d_geometry(int d, int P, int Bx, int By, int rx, int ry, int* Pg,
 
 extern "C" int mf_proj_kde2d_fwd(const float* x, int64_t n, int d, const float* V0, const float* V1, int P,
                                   const float* coords_x, int Bx, float sigma_x, int radius_x, const float* coords_y,
-                                  int By, float sigma_y, int radius_y, float* S, void* stream) {
+                                  int By, float sigma_y, int radius_y, float* S, void* ws, void* stream) {
     if (kde_check(n, d, P, Bx) || kde_check(n, d, P, By)) return 1;
-    int Pg;
-    size_t smem;
-    if (kde2d_geometry(d, P, Bx, By, radius_x, radius_y, &Pg, &smem, 0)) return 1;
-    if (hipMemsetAsync(S, 0, sizeof(float) * (size_t)P * Bx * By, (hipStream_t)stream) != hipSuccess) return fail("memset S");
-    if (n == 0) return 0;
-    const int ngroups = (P + Pg - 1) / Pg;
-    const int G = grid_for(n, KDE_BLOCK * 4, (NUM_CU * 8 + ngroups - 1) / ngroups);
-    ProfScope prof(PK_KDE2D_FWD, stream);
-    MF_ALLOW_DYN_SMEM(proj_kde2d_fwd_kernel, smem);
-    MF_LAUNCH(proj_kde2d_fwd_kernel, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V0, V1, P, Pg, coords_x, Bx,
-              1.0f / sigma_x, radius_x, coords_y, By, 1.0f / sigma_y, radius_y, S);
-    return check_launch("mf_proj_kde2d_fwd");
+    if (radius_x > KDE_RMAX2D || radius_y > KDE_RMAX2D)
+        return fail("2-D KDE kernel supports a truncation radius <= %d bins (bandwidth <= 0.6 bin widths)", KDE_RMAX2D);
+    const int BB = Bx * By;
+    const int budget = 18432;                         // 144 KiB of 64-bit bins
+    if (BB > budget) return fail("2-D histogram image %dx%d exceeds the LDS budget", Bx, By);
+    double* Sfix = reinterpret_cast<double*>(ws);
+    if (hipMemsetAsync(Sfix, 0, sizeof(double) * (size_t)P * BB, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
+    if (n > 0) {
+        int Pg = budget / BB;
+        if (Pg > P) Pg = P;
+        const int ds = d | 1;
+        const size_t smem = sizeof(u64) * (size_t)Pg * BB + sizeof(float) * (2 * (size_t)Pg * ds + Bx + By);
+        const int ngroups = (P + Pg - 1) / Pg;
+        int G = grid_for(n, KDE_BLOCK * 4, (NUM_CU * 8 + ngroups - 1) / ngroups);
+        if ((n + G - 1) / G > KDE_MAX_PER_WG) G = (int)((n + KDE_MAX_PER_WG - 1) / KDE_MAX_PER_WG);
+        ProfScope prof(PK_KDE2D_FWD, stream);
+        MF_ALLOW_DYN_SMEM(proj_kde2d_fwd_kernel, smem);
+        MF_LAUNCH(proj_kde2d_fwd_kernel, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V0, V1, P, Pg, coords_x, Bx,
+                  1.0f / sigma_x, radius_x, coords_y, By, 1.0f / sigma_y, radius_y, Sfix);
+        if (check_launch("mf_proj_kde2d_fwd")) return 1;
+    }
+    return fix_finish(Sfix, S, (int64_t)P * BB, stream);
 }
 
 extern "C" int mf_proj_kde2d_bwd(const float* x, int64_t n, int d, const float* V0, const float* V1, int P,

@@ -136,7 +136,8 @@ class AutoregressiveFlow(GenerativeModel):
                 raise RuntimeError(f"image layout mismatch: host {image_floats} vs library {expect}")
             self._spec = ops.FlowSpec(self.features, len(self.hidden_features), len(self.layers), self.kind, self.bins,
                                       image_floats, torch.from_numpy(image_index).to(dev),
-                                      torch.from_numpy(grad_index).to(dev))
+                                      torch.from_numpy(grad_index).to(dev),
+                                      [layer.order.cpu().tolist() for layer in self.layers])
             self._spec_device = dev
         return self._spec
 

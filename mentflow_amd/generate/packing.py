@@ -11,6 +11,14 @@ image (floats), hidden width 64, ``nblk`` output blocks of 64 padded rows (RQS: 
 Masked-out weights and padding carry index -1 (the gather writes 0 there) — this is where zuko's
 ``mask * weight`` (MaskedLinear.forward) happens: once per optimizer step, not once per call.
 
+Hidden-unit placement (mask sparsity).  zuko gives hidden unit u of every hidden layer the dependency class
+c_u = 1 + (u mod (d-1)) (masks.py).  The images place the hidden units SORTED BY CLASS: sorted position j sits in
+MFMA row  phys(j) = 32*((j>>1)>>4) + rowmap((j>>1)&15, j&1)  i.e. k-step s of the kernels covers sorted units
+(2s, 2s+1).  With that placement the autoregressive masks are block-triangular in k-step space: an output block of
+feature order o only needs the first ceil(cum[o]/2) k-steps (cum[c] = number of hidden units of class <= c), a hidden
+output tile only the k-steps up to its largest class, and the kernels skip the MFMAs that would multiply zeros
+(about half of them for d = 6).  Results equal the dense product up to fp32 summation order.
+
 Row permutation of the last layer.  The kernels evaluate the spline of feature i in the two lanes (col, col+32) of
 a particle; a lane half hh holds, in accumulator slot m (0..31), the MFMA row
     rho(hh, m) = 32*(m >> 4) + (m & 3) + 8*((m & 15) >> 2) + 4*hh.
@@ -39,6 +47,23 @@ def slot_of_row(r: int) -> Tuple[int, int]:
     hh = (rr >> 2) & 1
     m = 16 * (r >> 5) + (rr & 3) + 4 * (rr >> 3)
     return hh, m
+
+
+def hidden_placement(d: int, width: int = HID) -> np.ndarray:
+    """phys[u] = image row of hidden unit u (units sorted by dependency class, two per k-step)."""
+    cls = 1 + (np.arange(width) % (d - 1))
+    order = np.lexsort((np.arange(width), cls))          # sorted position j -> unit u
+    phys = np.empty(width, dtype=np.int64)
+    for j, u in enumerate(order):
+        s_, half = j >> 1, j & 1
+        phys[u] = 32 * (s_ >> 4) + rho(half, s_ & 15)
+    return phys
+
+
+def class_counts(d: int, width: int = HID) -> np.ndarray:
+    """cum[c] = number of hidden units with dependency class <= c, c = 0..d-1."""
+    cls = 1 + (np.arange(width) % (d - 1))
+    return np.array([(cls <= c).sum() for c in range(d)], dtype=np.int64)
 
 
 def image_layout(d: int, L: int, nblk: int) -> dict:
@@ -72,20 +97,21 @@ def layer_image_index(d: int, L: int, kind: str, K: int, masks: Sequence[torch.T
     nblk = d if kind == "rqs" else 1
     g = image_layout(d, L, nblk)
     idx = np.full(g["total"], -1, dtype=np.int64)
+    phys = hidden_placement(d)
     m0 = masks[0].numpy()
     for u in range(HID):
         for j in range(d):
             if m0[u, j]:
-                idx[g["offW0"] + u * g["S0"] + j] = offsets[0] + u * d + j
-        idx[g["offB0"] + u] = offsets[1] + u
+                idx[g["offW0"] + phys[u] * g["S0"] + j] = offsets[0] + u * d + j
+        idx[g["offB0"] + phys[u]] = offsets[1] + u
     for l in range(1, L):
         ml = masks[l].numpy()
         base = g["offWh"] + (l - 1) * (HID * WS + HID)
         for u in range(HID):
             for k in range(HID):
                 if ml[u, k]:
-                    idx[base + u * WS + k] = offsets[2 * l] + u * HID + k
-            idx[base + HID * WS + u] = offsets[2 * l + 1] + u
+                    idx[base + phys[u] * WS + phys[k]] = offsets[2 * l] + u * HID + k
+            idx[base + HID * WS + phys[u]] = offsets[2 * l + 1] + u
     mo = masks[L].numpy()
     for blk in range(nblk):
         for r in range(HID):
@@ -99,7 +125,7 @@ def layer_image_index(d: int, L: int, kind: str, K: int, masks: Sequence[torch.T
                 continue
             for k in range(HID):
                 if mo[row, k]:
-                    idx[g["offW3"] + (blk * HID + r) * WS + k] = offsets[2 * L] + row * HID + k
+                    idx[g["offW3"] + (blk * HID + r) * WS + phys[k]] = offsets[2 * L] + row * HID + k
             idx[g["offB3"] + blk * HID + r] = offsets[2 * L + 1] + row
     return idx.astype(np.int32)
 

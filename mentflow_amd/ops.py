@@ -6,6 +6,7 @@ raises otherwise): there is no CPU fallback.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import List, Optional, Sequence, Tuple
 
@@ -33,30 +34,35 @@ class FlowSpec:
     """Static description of a packed flow (shared by every call): geometry + device index maps."""
 
     def __init__(self, d: int, hidden_layers: int, transforms: int, kind: str, bins: int, image_floats: int,
-                 image_index: torch.Tensor, grad_index: torch.Tensor):
+                 image_index: torch.Tensor, grad_index: torch.Tensor, orders):
         self.d, self.L, self.T, self.kind, self.bins = d, hidden_layers, transforms, kind, bins
+        # per layer: host int32 array of the autoregressive order (lets the kernels skip masked-out MFMA k-steps)
+        self.orders = [(C.c_int32 * d)(*[int(v) for v in o]) for o in orders]
+        self.sparse = True
         self.image_floats = image_floats
         self.image_index = image_index      # int32 [T * image_floats]  -> flat parameter index or -1
         self.grad_index = grad_index        # int32 [numel]             -> position in the image stack or -1
         self.bwd_chunk = 1 << 19            # particles per backward chunk (3 KiB of scratch each at d=6)
 
 
-def _layer_fwd(spec: FlowSpec, image: torch.Tensor, x: torch.Tensor, y: torch.Tensor, logp_in: Optional[torch.Tensor],
-               logp_out: torch.Tensor, init: bool) -> None:
+def _layer_fwd(spec: FlowSpec, t: int, image: torch.Tensor, x: torch.Tensor, y: torch.Tensor,
+               logp_in: Optional[torch.Tensor], logp_out: torch.Tensor, init: bool) -> None:
     n = x.shape[0]
+    order = spec.orders[t] if spec.sparse else None
     if spec.kind == "rqs":
-        call("mf_flow_rqs_layer_fwd", ptr(image), spec.d, spec.L, spec.bins, ptr(x), n, ptr(y), ptr(logp_in),
+        call("mf_flow_rqs_layer_fwd", ptr(image), spec.d, spec.L, spec.bins, order, ptr(x), n, ptr(y), ptr(logp_in),
              ptr(logp_out), int(init), stream_ptr(x))
     else:
         call("mf_flow_affine_layer_fwd", ptr(image), spec.d, spec.L, ptr(x), n, ptr(y), ptr(logp_in), ptr(logp_out),
              int(init), stream_ptr(x))
 
 
-def _layer_bwd(spec: FlowSpec, image, x, gy, glogp, gx, gimage, scratch) -> None:
+def _layer_bwd(spec: FlowSpec, t: int, image, x, gy, glogp, gx, gimage, scratch) -> None:
     n = x.shape[0]
+    order = spec.orders[t] if spec.sparse else None
     if spec.kind == "rqs":
-        call("mf_flow_rqs_layer_bwd", ptr(image), spec.d, spec.L, spec.bins, ptr(x), n, ptr(gy), ptr(glogp), ptr(gx),
-             ptr(gimage), ptr(scratch), scratch.numel(), stream_ptr(x))
+        call("mf_flow_rqs_layer_bwd", ptr(image), spec.d, spec.L, spec.bins, order, ptr(x), n, ptr(gy), ptr(glogp),
+             ptr(gx), ptr(gimage), ptr(scratch), scratch.numel(), stream_ptr(x))
     else:
         call("mf_flow_affine_layer_bwd", ptr(image), spec.d, spec.L, ptr(x), n, ptr(gy), ptr(glogp), ptr(gx),
              ptr(gimage), ptr(scratch), scratch.numel(), stream_ptr(x))
@@ -86,7 +92,7 @@ class FlowSampleFn(torch.autograd.Function):
         xs = [z]
         for t in range(spec.T):
             y = torch.empty_like(z)
-            _layer_fwd(spec, images[t], xs[-1], y, logp, logp, t == 0)
+            _layer_fwd(spec, t, images[t], xs[-1], y, logp, logp, t == 0)
             xs.append(y)
         ctx.spec = spec
         ctx.grad_reduce = grad_reduce
@@ -111,7 +117,7 @@ class FlowSampleFn(torch.autograd.Function):
             gprev = torch.empty_like(g) if t > 0 else None
             for a in range(0, n, chunk):
                 b = min(n, a + chunk)
-                _layer_bwd(spec, images[t], xs[t][a:b], g[a:b], glogp[a:b], None if gprev is None else gprev[a:b],
+                _layer_bwd(spec, t, images[t], xs[t][a:b], g[a:b], glogp[a:b], None if gprev is None else gprev[a:b],
                            gimages[t], scratch)
             g = gprev
         gflat = torch.empty(spec.grad_index.numel(), dtype=_F32, device=dev)
@@ -130,7 +136,7 @@ def flow_layers_forward(z: torch.Tensor, flat: torch.Tensor, spec: FlowSpec) -> 
     xs = [z]
     for t in range(spec.T):
         y = torch.empty_like(z)
-        _layer_fwd(spec, images[t], xs[-1], y, logp, logp, t == 0)
+        _layer_fwd(spec, t, images[t], xs[-1], y, logp, logp, t == 0)
         xs.append(y)
     return xs, logp
 
@@ -148,8 +154,9 @@ class ProjKde1dFn(torch.autograd.Function):
         x, V, coords = _f32c(x), _f32c(V), _f32c(coords)
         P, B = V.shape[0], coords.numel()
         S = torch.empty(P, B, dtype=_F32, device=x.device)
+        ws = torch.empty(P * B, dtype=torch.int64, device=x.device)
         call("mf_proj_kde1d_fwd", ptr(x), x.shape[0], x.shape[1], ptr(V), P, ptr(coords), B, float(sigma), int(radius),
-             ptr(S), stream_ptr(x))
+             ptr(S), ptr(ws), stream_ptr(x))
         ctx.save_for_backward(x, V, coords)
         ctx.sigma, ctx.radius = float(sigma), int(radius)
         return S
@@ -171,8 +178,9 @@ class ProjKde2dFn(torch.autograd.Function):
         x, V0, V1, cx, cy = _f32c(x), _f32c(V0), _f32c(V1), _f32c(coords_x), _f32c(coords_y)
         P, Bx, By = V0.shape[0], cx.numel(), cy.numel()
         S = torch.empty(P, Bx, By, dtype=_F32, device=x.device)
+        ws = torch.empty(P * Bx * By, dtype=torch.int64, device=x.device)
         call("mf_proj_kde2d_fwd", ptr(x), x.shape[0], x.shape[1], ptr(V0), ptr(V1), P, ptr(cx), Bx, float(sigma_x),
-             int(radius_x), ptr(cy), By, float(sigma_y), int(radius_y), ptr(S), stream_ptr(x))
+             int(radius_x), ptr(cy), By, float(sigma_y), int(radius_y), ptr(S), ptr(ws), stream_ptr(x))
         ctx.save_for_backward(x, V0, V1, cx, cy)
         ctx.args = (float(sigma_x), float(sigma_y), int(radius_x), int(radius_y))
         return S
