@@ -177,6 +177,15 @@ __device__ __forceinline__ void input_layer(const float* W0, const float* b0, in
     relu2(h);
 }
 
+// exp(x) for |x| < ~80 as one v_exp_f32 with a compensated argument (x*log2(e) split into hi + lo so that the result
+// is good to ~1 ulp instead of |x| ulp); the library expf costs about three times as many VALU slots.
+__device__ __forceinline__ float fast_exp(float x) {
+    const float L2E = 1.4426950408889634f;
+    const float hi = x * L2E;
+    const float lo = fmaf(x, L2E, -hi) + x * 1.925963033500810e-8f;     // rounding error of hi + low bits of log2(e)
+    return __builtin_amdgcn_exp2f(hi) * fmaf(lo, 0.6931471805599453f, 1.0f);
+}
+
 __device__ __forceinline__ float soft_clip(float v, float a) { return v * fast_rcp(fmaf(fabsf(v), a, 1.0f)); }
 __device__ __forceinline__ float soft_clip_grad(float v, float a) {
     const float ia = fast_rcp(fmaf(fabsf(v), a, 1.0f));
@@ -198,32 +207,29 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
     constexpr float A1 = LOG_SLOPE_INV;
     static_assert(K + KD0 <= 32, "spline does not fit the 32 slots of a lane half");
 
-    // soft clip + softmax over this half's K logits
+    // soft clip + softmax over this half's K logits.  The clipped logits lie in (-3.46, 3.46), so exp() cannot
+    // overflow and the usual max subtraction (a no-op mathematically) is not needed.
     float p[K];
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int m = 0; m < K; ++m) {
-        p[m] = soft_clip(v[m], A2);
-        mx = fmaxf(mx, p[m]);
-    }
     float sum = 0.0f;
 #pragma unroll
     for (int m = 0; m < K; ++m) {
-        p[m] = expf(p[m] - mx);
+        p[m] = fast_exp(soft_clip(v[m], A2));
         sum += p[m];
     }
     const float inv = 1.0f / sum;
-    // cumulative probabilities (torch.cumsum on CPU accumulates in double) and the bin search on the widths
+    // cumulative probabilities (torch.cumsum on CPU accumulates in double) and the bin search on the widths, done on
+    // the cumulative probabilities: knot_j < x  <=>  c_j < (x / bound + 1) / 2
     float cj[K + 1];
     cj[0] = 0.0f;
     double c = 0.0;
+    const float xc = fmaf(x, 0.5f / RQS_BOUND, 0.5f);
     int cnt = (-RQS_BOUND < x) ? 1 : 0;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         p[j] *= inv;
         c += (double)p[j];
         cj[j + 1] = (float)c;
-        cnt += (RQS_BOUND * (2.0f * cj[j + 1] - 1.0f) < x) ? 1 : 0;
+        cnt += (cj[j + 1] < xc) ? 1 : 0;
     }
     cnt = __shfl_xor(cnt, 32) * hh + cnt * (1 - hh);          // the count of half 0 (widths) for both lanes
     const int k = cnt - 1;
@@ -253,8 +259,8 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
     }
     r0 += __shfl_xor(r0, 32);
     r1 += __shfl_xor(r1, 32);
-    const float d0 = expf(soft_clip(r0, A1));
-    const float d1 = expf(soft_clip(r1, A1));
+    const float d0 = fast_exp(soft_clip(r0, A1));
+    const float d1 = fast_exp(soft_clip(r1, A1));
 
     const float w = x1 - x0;
     const float iw = fast_rcp(w);
@@ -385,25 +391,22 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __res
     }
 }
 
-// scratch rows: 64 floats per particle; column c = 32*rt + 16*hh + r holds accumulator register r of row tile rt of
-// lane half hh, i.e. MFMA row 32*rt + rowmap(r, hh): memory tile (c >> 5) == MFMA row tile, so the parameter-gradient
-// contraction can skip whole 32-column tiles that the autoregressive masks zero out.
-__device__ __forceinline__ void store_row(float* __restrict__ dst, int64_t p, int hh, const float (&v)[32]) {
+// scratch buffers are stored as transposed 32-particle tiles:  X[tile][c][particle]  (64 x 32 floats = 8 KiB per
+// tile), column c = 32*rt + 16*hh + r <-> accumulator register r of row tile rt of lane half hh = MFMA row
+// 32*rt + rowmap(r, hh).  The parameter-gradient contraction (particles = MFMA k) then reads, per lane, 16 consecutive
+// particles of one column as four 16-byte loads, and memory tile (c >> 5) == MFMA row tile so masked-out tiles can be
+// skipped.  A store instruction writes two 128-byte segments (the two lane halves).
+__device__ __forceinline__ void store_tile(float* __restrict__ dst, int64_t tile, int col, int hh, const float (&v)[32]) {
+    float* base = dst + tile * 2048 + (16 * hh) * 32 + col;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        float4* q = reinterpret_cast<float4*>(dst + p * 64 + 32 * rt + 16 * hh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            q[j] = make_float4(v[16 * rt + 4 * j], v[16 * rt + 4 * j + 1], v[16 * rt + 4 * j + 2], v[16 * rt + 4 * j + 3]);
-    }
+    for (int m = 0; m < 32; ++m) base[(32 * (m >> 4) + (m & 15)) * 32] = v[m];
 }
-__device__ __forceinline__ void store_row(float* __restrict__ dst, int64_t p, int hh, const f32x16_t (&a)[2]) {
+__device__ __forceinline__ void store_tile(float* __restrict__ dst, int64_t tile, int col, int hh, const f32x16_t (&a)[2]) {
+    float* base = dst + tile * 2048 + (16 * hh) * 32 + col;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        float4* q = reinterpret_cast<float4*>(dst + p * 64 + 32 * rt + 16 * hh);
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q[j] = make_float4(a[rt][4 * j], a[rt][4 * j + 1], a[rt][4 * j + 2], a[rt][4 * j + 3]);
-    }
+        for (int r = 0; r < 16; ++r) base[(32 * rt + r) * 32] = a[rt][r];
 }
 
 // =========================================================================================== backward, RQS
@@ -436,13 +439,13 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
         // ---- recompute the trunk, keep every activation
         f32x16_t h[L][2];
         input_layer(lds + g.offW0, lds + g.offB0, g.S0, d, xb, h[0], col, hh);
-        store_row(ACT, p, hh, h[0]);
+        store_tile(ACT, tile, col, hh, h[0]);
 #pragma unroll
         for (int l = 1; l < L; ++l) {
             const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
             linear64(W, W + HID * WS, h[l - 1], h[l], col, hh, sp.kend_h[0], sp.kend_h[1]);
             relu2(h[l]);
-            store_row(ACT + (int64_t)l * npad * 64, p, hh, h[l]);
+            store_tile(ACT + (int64_t)l * npad * 64, tile, col, hh, h[l]);
         }
         // ---- output blocks: spline forward + adjoint, accumulate dL/dh_last
         f32x16_t gh[2];
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
             // direct path dL/dx_i goes into row i of the dL/dx accumulator tile (row = 4*hh + reg for rows < 8)
 #pragma unroll
             for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
-            store_row(GPHI + (int64_t)i * npad * 64, p, hh, gv);
+            store_tile(GPHI + (int64_t)i * npad * 64, tile, col, hh, gv);
             // gh += W3_i^T gphi   (contraction over the 64 padded output rows = slots of both halves); hidden tile 1
             // only receives something if block i sees more than 32 hidden units, nothing at all for a pure-bias block
 #pragma unroll
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gh[rt][r] = (h[l][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
-            store_row(GPRE + (int64_t)l * npad * 64, p, hh, gh);
+            store_tile(GPRE + (int64_t)l * npad * 64, tile, col, hh, gh);
             f32x16_t t[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) gh[rt][r] = (h[0][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
-        store_row(GPRE, p, hh, gh);
+        store_tile(GPRE, tile, col, hh, gh);
         if (gx != nullptr) {
             // gacc += W0^T gpre0 : rows = input features (lanes col < d carry weights, others 0)
             const float* wcol = lds + g.offW0 + 4 * hh * g.S0 + col;
@@ -525,50 +528,47 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
 }
 
 // =========================================================================================== parameter gradients
-// C[a][b] = sum_p A[p][a] * B[p][b] over particles (MFMA k = particle), bias[a] = sum_p A[p][a].
-// grid (G, njobs); job 0: A = GPRE[0], B = x (d columns); job j in 1..L-1: A = GPRE[j], B = ACT[j-1];
-// job L+i: A = GPHI[i], B = ACT[L-1].  Results are added (float atomics) into gimage in image coordinates.
-constexpr int OA_BLOCK = 256;
-__global__ __launch_bounds__(OA_BLOCK) void outer_accum_kernel(const float* __restrict__ scratch,
-                                                               const float* __restrict__ x, int64_t n, int d, int L,
-                                                               int nblk, float* __restrict__ gimage, Sparsity sp) {
-    __shared__ float tileC[64 * 64];
-    __shared__ float tileB[64];
+// C[a][b] = sum_p A[p][a] * B[p][b] over particles (MFMA k = particle), bias[a] = sum_p A[p][a], for every linear
+// layer of the conditioner.  grid (G, 2): blockIdx.y = 0 -> the `nblk` output blocks of the last layer (wave w owns
+// block w: A = GPHI[w], B = ACT[L-1] shared by all waves of the workgroup through L1/L2);  blockIdx.y = 1 -> the trunk
+// (wave 0: A = GPRE[0], B = x;  wave l: A = GPRE[l], B = ACT[l-1]).  Every wave keeps its 64x64 result in 64
+// accumulator registers over all the tiles it visits and adds it to gimage (image coordinates) with float atomics.
+constexpr int OA_MAX_WAVES = 8;
+__global__ __launch_bounds__(64 * OA_MAX_WAVES) void outer_accum_kernel(const float* __restrict__ scratch,
+                                                                        const float* __restrict__ x, int64_t n, int d,
+                                                                        int L, int nblk, float* __restrict__ gimage,
+                                                                        Sparsity sp) {
     const ImageLayout g = image_layout(d, L, nblk);
     const int64_t ntiles = (n + 31) / 32;
     const int64_t npad = ntiles * 32;
     const float* ACT = scratch;
     const float* GPRE = ACT + (int64_t)L * npad * 64;
     const float* GPHI = GPRE + (int64_t)L * npad * 64;
-    const int job = blockIdx.y;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
     const float* A;
     const float* B = nullptr;
     int offW, offB, strideW;
     bool need_b0 = true, need_b1 = true;       // which 32-column tiles of B can be non-zero
-    if (job == 0) {
-        A = GPRE;
-        offW = g.offW0; offB = g.offB0; strideW = g.S0;
-        need_b1 = false;
-    } else if (job < L) {
-        A = GPRE + (int64_t)job * npad * 64;
-        B = ACT + (int64_t)(job - 1) * npad * 64;
-        offW = g.offWh + (job - 1) * (HID * WS + HID); offB = offW + HID * WS; strideW = WS;
-    } else {
-        const int i = job - L;
-        A = GPHI + (int64_t)i * npad * 64;
+    bool from_x = false;
+    if (blockIdx.y == 0) {
+        if (wid >= nblk) return;
+        A = GPHI + (int64_t)wid * npad * 64;
         B = ACT + (int64_t)(L - 1) * npad * 64;
-        offW = g.offW3 + i * HID * WS; offB = g.offB3 + i * HID; strideW = WS;
-        need_b0 = sp.kend3[i] > 0;
-        need_b1 = sp.rt1[i] != 0;
+        offW = g.offW3 + wid * HID * WS; offB = g.offB3 + wid * HID; strideW = WS;
+        need_b0 = sp.kend3[wid] > 0;
+        need_b1 = sp.rt1[wid] != 0;
+    } else {
+        if (wid >= L) return;
+        A = GPRE + (int64_t)wid * npad * 64;
+        if (wid == 0) {
+            from_x = true;
+            need_b1 = false;
+            offW = g.offW0; offB = g.offB0; strideW = g.S0;
+        } else {
+            B = ACT + (int64_t)(wid - 1) * npad * 64;
+            offW = g.offWh + (wid - 1) * (HID * WS + HID); offB = offW + HID * WS; strideW = WS;
+        }
     }
-    for (int i = threadIdx.x; i < 64 * 64; i += OA_BLOCK) tileC[i] = 0.0f;
-    if (threadIdx.x < 64) tileB[threadIdx.x] = 0.0f;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
-    // particle pairs (k-steps) are dealt round-robin to the waves of the grid
-    const int64_t nsteps = npad / 2;
-    const int64_t wave_global = (int64_t)blockIdx.x * (OA_BLOCK / 64) + wid;
-    const int64_t wave_count = (int64_t)gridDim.x * (OA_BLOCK / 64);
     f32x16_t acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -577,53 +577,95 @@ __global__ __launch_bounds__(OA_BLOCK) void outer_accum_kernel(const float* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     float bsum0 = 0.0f, bsum1 = 0.0f;
-    for (int64_t s = wave_global; s < nsteps; s += wave_count) {
-        const int64_t p = 2 * s + hh;
-        const float a0 = A[p * 64 + col], a1 = A[p * 64 + 32 + col];
-        float b0, b1;
-        if (job == 0) {
-            b0 = (col < d && p < n) ? x[p * d + col] : 0.0f;
-            b1 = 0.0f;
+    // lane (col, hh): column 32*t + col, particles 16*hh + s (s = 0..15): k-step s pairs particles (s, 16 + s).
+    // The fragments of the next tile are loaded while the MFMAs of the current one run (register double buffer).
+    auto load_tile = [&](int64_t tile, float4 (&a0)[4], float4 (&a1)[4], float4 (&b0)[4], float4 (&b1)[4]) {
+        const float4* pa0 = reinterpret_cast<const float4*>(A + tile * 2048 + col * 32 + 16 * hh);
+        const float4* pa1 = reinterpret_cast<const float4*>(A + tile * 2048 + (32 + col) * 32 + 16 * hh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a0[q] = pa0[q];
+            a1[q] = pa1[q];
+        }
+        if (from_x) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t p = tile * 32 + 16 * hh + 4 * q + e;
+                    t[e] = (col < d && p < n) ? x[p * d + col] : 0.0f;
+                }
+                b0[q] = make_float4(t[0], t[1], t[2], t[3]);
+                b1[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
         } else {
-            b0 = B[p * 64 + col];
-            b1 = B[p * 64 + 32 + col];
+            const float4* pb0 = reinterpret_cast<const float4*>(B + tile * 2048 + col * 32 + 16 * hh);
+            const float4* pb1 = reinterpret_cast<const float4*>(B + tile * 2048 + (32 + col) * 32 + 16 * hh);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                b0[q] = need_b0 ? pb0[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                b1[q] = need_b1 ? pb1[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
         }
-        bsum0 += a0;
-        bsum1 += a1;
-        if (need_b0) {
-            acc[0][0] = mfma(a0, b0, acc[0][0]);
-            acc[1][0] = mfma(a1, b0, acc[1][0]);
+    };
+    auto compute_tile = [&](const float4 (&a0)[4], const float4 (&a1)[4], const float4 (&b0)[4], const float4 (&b1)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float av0[4] = {a0[q].x, a0[q].y, a0[q].z, a0[q].w};
+            const float av1[4] = {a1[q].x, a1[q].y, a1[q].z, a1[q].w};
+            const float bv0[4] = {b0[q].x, b0[q].y, b0[q].z, b0[q].w};
+            const float bv1[4] = {b1[q].x, b1[q].y, b1[q].z, b1[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bsum0 += av0[e];
+                bsum1 += av1[e];
+                if (need_b0) {
+                    acc[0][0] = mfma(av0[e], bv0[e], acc[0][0]);
+                    acc[1][0] = mfma(av1[e], bv0[e], acc[1][0]);
+                }
+                if (need_b1) {
+                    acc[0][1] = mfma(av0[e], bv1[e], acc[0][1]);
+                    acc[1][1] = mfma(av1[e], bv1[e], acc[1][1]);
+                }
+            }
         }
-        if (need_b1) {
-            acc[0][1] = mfma(a0, b1, acc[0][1]);
-            acc[1][1] = mfma(a1, b1, acc[1][1]);
-        }
+    };
+    float4 ua0[4], ua1[4], ub0[4], ub1[4], va0[4], va1[4], vb0[4], vb1[4];
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile, ua0, ua1, ub0, ub1);
+    while (tile < ntiles) {
+        const int64_t t1 = tile + gridDim.x;
+        if (t1 < ntiles) load_tile(t1, va0, va1, vb0, vb1);
+        compute_tile(ua0, ua1, ub0, ub1);
+        if (t1 >= ntiles) break;
+        const int64_t t2 = t1 + gridDim.x;
+        if (t2 < ntiles) load_tile(t2, ua0, ua1, ub0, ub1);
+        compute_tile(va0, va1, vb0, vb1);
+        tile = t2;
     }
-    // memory column c = 32*rt + 16*hc + r  <->  physical (image) row rho = 32*rt + rowmap(r, hc)
+    // memory column c = 32*rt + 16*hc + r  <->  image row rho = 32*rt + rowmap(r, hc)
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
-            const int rhoB = (job == 0) ? col : (32 * tb + rowmap(col & 15, col >> 4));
+            if (!(tb ? need_b1 : need_b0)) continue;
+            const int rhoB = from_x ? col : (32 * tb + rowmap(col & 15, col >> 4));
+            if (from_x && col >= d) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int wA = rowmap(r, hh);                       // C row within the tile = memory column of A
                 const int rhoA = 32 * ta + rowmap(wA & 15, wA >> 4);
-                if (tb ? need_b1 : need_b0) atomicAdd(&tileC[rhoA * 64 + rhoB], acc[ta][tb][r]);
+                atomicAdd(&gimage[offW + rhoA * strideW + rhoB], acc[ta][tb][r]);
             }
         }
-    {
+    bsum0 += __shfl_xor(bsum0, 32);
+    bsum1 += __shfl_xor(bsum1, 32);
+    if (hh == 0) {
         const int rho = rowmap(col & 15, col >> 4);
-        atomicAdd(&tileB[rho], bsum0);
-        atomicAdd(&tileB[32 + rho], bsum1);
+        atomicAdd(&gimage[offB + rho], bsum0);
+        atomicAdd(&gimage[offB + 32 + rho], bsum1);
     }
-    __syncthreads();
-    const int ncolsB = (job == 0) ? d : 64;
-    for (int i = threadIdx.x; i < 64 * 64; i += OA_BLOCK) {
-        const int ra = i >> 6, cb = i & 63;
-        if (cb < ncolsB) atomicAdd(&gimage[offW + ra * strideW + cb], tileC[i]);
-    }
-    if (threadIdx.x < 64) atomicAdd(&gimage[offB + threadIdx.x], tileB[threadIdx.x]);
 }
 
 static int flow_check(int d, int L, int64_t n) {
@@ -709,13 +751,12 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
         return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: bins in {8,20}, hidden_layers in {2,3})",
                     bins, hidden_layers);
     if (check_launch("mf_flow_rqs_layer_bwd")) return 1;
-    const int64_t npad = ((n + 31) / 32) * 32;
-    int64_t G = npad / 2 / 64;
-    if (G < 1) G = 1;
-    if (G > 128) G = 128;
-    const int njobs = hidden_layers + d;
+    const int64_t ntiles = (n + 31) / 32;
+    int64_t G = ntiles < 4 * NUM_CU ? ntiles : 4 * NUM_CU;
+    const int nwaves = d > hidden_layers ? d : hidden_layers;
+    if (nwaves > OA_MAX_WAVES) return fail("too many linear blocks for the gradient kernel");
     ProfScope prof(PK_OUTER_ACCUM, stream);
-    MF_LAUNCH(outer_accum_kernel, dim3((unsigned)G, njobs), OA_BLOCK, 0, stream, (const float*)scratch, x, n, d,
+    MF_LAUNCH(outer_accum_kernel, dim3((unsigned)G, 2), 64 * nwaves, 0, stream, (const float*)scratch, x, n, d,
               hidden_layers, d, gimage, sp);
     return check_launch("mf_flow_rqs_layer_bwd(outer_accum)");
 }
