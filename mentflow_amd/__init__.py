@@ -13,5 +13,6 @@ from . import loss
 from . import ops
 from . import prior
 from . import simulate
+from . import train
 from . import utils
 from .utils import unravel
