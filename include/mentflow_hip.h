@@ -68,6 +68,17 @@ int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins
                           const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gimage,
                           float* scratch, int64_t scratch_floats, void* stream);
 
+/* Affine (MAF) variant: zuko MonotonicAffineTransform, y = x*exp(s~)+t, s~ = s/(1+|s/log(1e-3)|), ladj = s~
+ * (mentflow/generate/build.py:28 "maf"; BASELINE config C1).  Same image layout with ONE output block whose slot i of
+ * lane half 0 is shift_i and of half 1 is scale_i.                                                             */
+int64_t mf_flow_affine_image_floats(int d, int hidden_layers);
+int64_t mf_flow_affine_bwd_scratch_floats(int64_t n, int hidden_layers);
+int mf_flow_affine_layer_fwd(const float* image, int d, int hidden_layers, const int32_t* order, const float* x,
+                             int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp, void* stream);
+int mf_flow_affine_layer_bwd(const float* image, int d, int hidden_layers, const int32_t* order, const float* x,
+                             int64_t n, const float* gy, const float* glogp, float* gx, float* gimage, float* scratch,
+                             int64_t scratch_floats, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Fused linear projection + 1-D Gaussian-KDE histogram over P projections.
  * Replaces, for all P transforms at once: `x.clone() @ M.T` (mentflow/simulate/transform.py:67-68, only the

@@ -527,6 +527,171 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
     }
 }
 
+// =========================================================================================== affine (MAF) layers
+// zuko MonotonicAffineTransform: y = x * exp(s~) + t, s~ = s / (1 + |s / log(1e-3)|), ladj = s~  (build.py:28 "maf").
+// One output block: slot i of lane half 0 = shift_i, of half 1 = scale_i (row tile 0 only; tile 1 is padding).
+template <int L, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void affine_layer_fwd_kernel(const float* __restrict__ image, int d,
+                                                                 const float* __restrict__ x, int64_t n,
+                                                                 float* __restrict__ y, const float* __restrict__ logp_in,
+                                                                 float* __restrict__ logp_out, int init_logp, Sparsity sp) {
+    MF_DYN_SMEM(float, lds);
+    const ImageLayout g = image_layout(d, L, 1);
+    stage_image<BLOCK>(lds, image, g.total);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+    const int64_t ntiles = (n + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (BLOCK / 64)) {
+        MF_NO_HOIST();
+        const int64_t p = tile * 32 + col;
+        const bool valid = p < n;
+        const float* xp = x + (valid ? p : n - 1) * d;
+        float xb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xb[s] = (2 * s + hh < d) ? xp[2 * s + hh] : 0.0f;
+        f32x16_t h[2];
+        input_layer(lds + g.offW0, lds + g.offB0, g.S0, d, xb, h, col, hh);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            f32x16_t t[2];
+            const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
+            linear64(W, W + HID * WS, h, t, col, hh, sp.kend_h[0], sp.kend_h[1]);
+            relu2(t);
+            h[0] = t[0];
+            h[1] = t[1];
+        }
+        f32x16_t phi[2];
+        linear64(lds + g.offW3, lds + g.offB3, h, phi, col, hh, 32, 0);
+        float ladj = 0.0f;
+#pragma unroll
+        for (int i = 0; i < FLOW_DMAX + 1; ++i) {
+            if (i < d) {
+                const float mine = phi[0][i];
+                const float other = __shfl_xor(mine, 32);
+                const float shift = hh ? other : mine, scale = hh ? mine : other;
+                const float ls = soft_clip(scale, LOG_SLOPE_INV);
+                ladj += ls;
+                if (valid && hh == 0) y[p * d + i] = fmaf(xp[i], fast_exp(ls), shift);
+            }
+        }
+        if (valid && hh == 0) {
+            const float lp0 = init_logp ? base_log_prob(xp, d) : logp_in[p];
+            logp_out[p] = lp0 - ladj;
+        }
+    }
+}
+
+// scratch: ACT[L][npad][64] | GPRE[L][npad][64] | GPHI[1][npad][64]
+template <int L>
+__global__ __launch_bounds__(FLOW_BLOCK) void affine_layer_bwd_kernel(const float* __restrict__ image, int d,
+                                                                      const float* __restrict__ x, int64_t n,
+                                                                      const float* __restrict__ gy,
+                                                                      const float* __restrict__ glogp, float* __restrict__ gx,
+                                                                      float* __restrict__ scratch, Sparsity sp) {
+    MF_DYN_SMEM(float, lds);
+    const ImageLayout g = image_layout(d, L, 1);
+    stage_image(lds, image, g.total);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+    const int64_t ntiles = (n + 31) / 32;
+    const int64_t npad = ntiles * 32;
+    float* ACT = scratch;
+    float* GPRE = ACT + (int64_t)L * npad * 64;
+    float* GPHI = GPRE + (int64_t)L * npad * 64;
+    for (int64_t tile = (int64_t)blockIdx.x * FLOW_WAVES + wid; tile < ntiles; tile += (int64_t)gridDim.x * FLOW_WAVES) {
+        MF_NO_HOIST();
+        const int64_t p = tile * 32 + col;
+        const bool valid = p < n;
+        const int64_t pc = valid ? p : n - 1;
+        const float* xp = x + pc * d;
+        float xb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xb[s] = (2 * s + hh < d) ? xp[2 * s + hh] : 0.0f;
+        f32x16_t h[L][2];
+        input_layer(lds + g.offW0, lds + g.offB0, g.S0, d, xb, h[0], col, hh);
+        store_tile(ACT, tile, col, hh, h[0]);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
+            linear64(W, W + HID * WS, h[l - 1], h[l], col, hh, sp.kend_h[0], sp.kend_h[1]);
+            relu2(h[l]);
+            store_tile(ACT + (int64_t)l * npad * 64, tile, col, hh, h[l]);
+        }
+        f32x16_t phi[2];
+        linear64(lds + g.offW3, lds + g.offB3, h[L - 1], phi, col, hh, 32, 0);
+        const float gl = valid ? -glogp[pc] : 0.0f;
+        f32x16_t gacc;
+        float gv[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gacc[r] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) gv[m] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < FLOW_DMAX + 1; ++i) {
+            if (i < d) {
+                const float mine = phi[0][i];
+                const float other = __shfl_xor(mine, 32);
+                const float scale = hh ? mine : other;
+                const float ls = soft_clip(scale, LOG_SLOPE_INV);
+                const float e = fast_exp(ls);
+                const float gyi = valid ? gy[pc * d + i] : 0.0f;
+                const float gls = fmaf(gyi * xp[i], e, gl);               // dL/ds~ : through y and through ladj
+                gv[i] = hh ? gls * soft_clip_grad(scale, LOG_SLOPE_INV) : gyi;
+                const float gxd = gyi * e;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
+            }
+        }
+        store_tile(GPHI, tile, col, hh, gv);
+        // gh = W3^T gphi: only the 16 slots of row tile 0 are populated
+        f32x16_t gh[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const float* wcol = lds + g.offW3 + 4 * hh * WS + 32 * rt + col;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = mfma(wcol[rowmap(s, 0) * WS], gv[s], acc);
+            gh[rt] = acc;
+        }
+#pragma unroll
+        for (int l = L - 1; l >= 1; --l) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gh[rt][r] = (h[l][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
+            store_tile(GPRE + (int64_t)l * npad * 64, tile, col, hh, gh);
+            f32x16_t t[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                t[0][r] = 0.0f;
+                t[1][r] = 0.0f;
+            }
+            linear64_t(lds + g.offWh + (l - 1) * (HID * WS + HID), gh, t, col, hh, sp.kbeg_ht[0], sp.kbeg_ht[1]);
+            gh[0] = t[0];
+            gh[1] = t[1];
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gh[rt][r] = (h[0][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
+        store_tile(GPRE, tile, col, hh, gh);
+        if (gx != nullptr) {
+            const float* wcol = lds + g.offW0 + 4 * hh * g.S0 + col;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
+                const float a = (col < d) ? wcol[kk * g.S0] : 0.0f;
+                gacc = mfma(a, gh[s >> 4][s & 15], gacc);
+            }
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * hh + j < d) gx[p * d + 4 * hh + j] = gacc[j];
+            }
+        }
+    }
+}
+
 // =========================================================================================== parameter gradients
 // C[a][b] = sum_p A[p][a] * B[p][b] over particles (MFMA k = particle), bias[a] = sum_p A[p][a], for every linear
 // layer of the conditioner.  grid (G, 2): blockIdx.y = 0 -> the `nblk` output blocks of the last layer (wave w owns
@@ -759,4 +924,63 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
     MF_LAUNCH(outer_accum_kernel, dim3((unsigned)G, 2), 64 * nwaves, 0, stream, (const float*)scratch, x, n, d,
               hidden_layers, d, gimage, sp);
     return check_launch("mf_flow_rqs_layer_bwd(outer_accum)");
+}
+
+// ------------------------------------------------------------------------------------------------ affine C ABI
+extern "C" int64_t mf_flow_affine_image_floats(int d, int hidden_layers) { return image_layout(d, hidden_layers, 1).total; }
+
+extern "C" int64_t mf_flow_affine_bwd_scratch_floats(int64_t n, int hidden_layers) {
+    const int64_t npad = ((n + 31) / 32) * 32;
+    return (2 * (int64_t)hidden_layers + 1) * npad * 64;
+}
+
+#define MF_AFFINE_CASES(X) X(3) X(2)
+
+extern "C" int mf_flow_affine_layer_fwd(const float* image, int d, int hidden_layers, const int32_t* order, const float* x,
+                                         int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp,
+                                         void* stream) {
+    if (flow_check(d, hidden_layers, n)) return 1;
+    if (n == 0) return 0;
+    const Sparsity sp = make_sparsity(d, order, 1);
+    const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, 1).total;
+#define X(LL)                                                                                                         \
+    if (hidden_layers == LL) {                                                                                        \
+        ProfScope prof(PK_FLOW_FWD, stream);                                                                          \
+        MF_ALLOW_DYN_SMEM((affine_layer_fwd_kernel<LL, 1024>), smem);                                                 \
+        MF_LAUNCH((affine_layer_fwd_kernel<LL, 1024>), flow_grid(n, 16), 1024, smem, stream, image, d, x, n, y, logp_in, \
+                  logp_out, init_logp, sp);                                                                           \
+        return check_launch("mf_flow_affine_layer_fwd");                                                              \
+    }
+    MF_AFFINE_CASES(X)
+#undef X
+    return fail("no affine kernel instance for hidden_layers=%d (built: 2, 3)", hidden_layers);
+}
+
+extern "C" int mf_flow_affine_layer_bwd(const float* image, int d, int hidden_layers, const int32_t* order, const float* x,
+                                         int64_t n, const float* gy, const float* glogp, float* gx, float* gimage,
+                                         float* scratch, int64_t scratch_floats, void* stream) {
+    if (flow_check(d, hidden_layers, n)) return 1;
+    if (n == 0) return 0;
+    if (scratch_floats < mf_flow_affine_bwd_scratch_floats(n, hidden_layers)) return fail("scratch too small");
+    const Sparsity sp = make_sparsity(d, order, 1);
+    const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, 1).total;
+    bool launched = false;
+#define X(LL)                                                                                                         \
+    if (!launched && hidden_layers == LL) {                                                                           \
+        ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
+        MF_ALLOW_DYN_SMEM((affine_layer_bwd_kernel<LL>), smem);                                                       \
+        MF_LAUNCH((affine_layer_bwd_kernel<LL>), flow_grid(n), FLOW_BLOCK, smem, stream, image, d, x, n, gy, glogp, gx, \
+                  scratch, sp);                                                                                       \
+        launched = true;                                                                                              \
+    }
+    MF_AFFINE_CASES(X)
+#undef X
+    if (!launched) return fail("no affine kernel instance for hidden_layers=%d (built: 2, 3)", hidden_layers);
+    if (check_launch("mf_flow_affine_layer_bwd")) return 1;
+    const int64_t ntiles = (n + 31) / 32;
+    int64_t G = ntiles < 4 * NUM_CU ? ntiles : 4 * NUM_CU;
+    ProfScope prof(PK_OUTER_ACCUM, stream);
+    MF_LAUNCH(outer_accum_kernel, dim3((unsigned)G, 2), 64 * hidden_layers, 0, stream, (const float*)scratch, x, n, d,
+              hidden_layers, 1, gimage, sp);
+    return check_launch("mf_flow_affine_layer_bwd(outer_accum)");
 }

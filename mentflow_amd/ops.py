@@ -53,8 +53,8 @@ def _layer_fwd(spec: FlowSpec, t: int, image: torch.Tensor, x: torch.Tensor, y: 
         call("mf_flow_rqs_layer_fwd", ptr(image), spec.d, spec.L, spec.bins, order, ptr(x), n, ptr(y), ptr(logp_in),
              ptr(logp_out), int(init), stream_ptr(x))
     else:
-        call("mf_flow_affine_layer_fwd", ptr(image), spec.d, spec.L, ptr(x), n, ptr(y), ptr(logp_in), ptr(logp_out),
-             int(init), stream_ptr(x))
+        call("mf_flow_affine_layer_fwd", ptr(image), spec.d, spec.L, order, ptr(x), n, ptr(y), ptr(logp_in),
+             ptr(logp_out), int(init), stream_ptr(x))
 
 
 def _layer_bwd(spec: FlowSpec, t: int, image, x, gy, glogp, gx, gimage, scratch) -> None:
@@ -64,7 +64,7 @@ def _layer_bwd(spec: FlowSpec, t: int, image, x, gy, glogp, gx, gimage, scratch)
         call("mf_flow_rqs_layer_bwd", ptr(image), spec.d, spec.L, spec.bins, order, ptr(x), n, ptr(gy), ptr(glogp),
              ptr(gx), ptr(gimage), ptr(scratch), scratch.numel(), stream_ptr(x))
     else:
-        call("mf_flow_affine_layer_bwd", ptr(image), spec.d, spec.L, ptr(x), n, ptr(gy), ptr(glogp), ptr(gx),
+        call("mf_flow_affine_layer_bwd", ptr(image), spec.d, spec.L, order, ptr(x), n, ptr(gy), ptr(glogp), ptr(gx),
              ptr(gimage), ptr(scratch), scratch.numel(), stream_ptr(x))
 
 
@@ -110,7 +110,10 @@ class FlowSampleFn(torch.autograd.Function):
         glogp = torch.zeros(n, dtype=_F32, device=dev) if glogp is None else _f32c(glogp)
         gimages = torch.zeros_like(images)
         chunk = min(n, spec.bwd_chunk)
-        scratch_floats = _lib.get_lib().mf_flow_bwd_scratch_floats(chunk, spec.d, spec.L)
+        if spec.kind == "rqs":
+            scratch_floats = _lib.get_lib().mf_flow_bwd_scratch_floats(chunk, spec.d, spec.L)
+        else:
+            scratch_floats = _lib.get_lib().mf_flow_affine_bwd_scratch_floats(chunk, spec.L)
         scratch = torch.empty(max(scratch_floats, 1), dtype=_F32, device=dev)
         g = gx
         for t in reversed(range(spec.T)):

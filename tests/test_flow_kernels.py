@@ -109,3 +109,31 @@ def test_full_train_step_matches_oracle(backend):
     assert (torch.stack(D).cpu() - torch.stack(Do)).abs().max() < 2e-6 + 2e-4 * float(torch.stack(Do).abs().max())
     assert abs(float(L) - float(Lo)) < 1e-4 + 500 * 2e-6
     assert (g.double() - go).abs().max() < 2e-3 * go.abs().max()
+
+
+@pytest.mark.parametrize("d", [2, 6])
+def test_maf_affine_forward_backward_match_oracle(backend, d):
+    """BASELINE config C1's "affine coupling" flow: zuko MAF (MonotonicAffineTransform)."""
+    gen = make_generator(backend, d, kind="maf", transforms=3)
+    assert sum(p.numel() for p in gen.parameters()) == 3 * (64 * d + 64 + 2 * (64 * 64 + 64) + 2 * d * 64 + 2 * d)
+    torch.manual_seed(5)
+    n = 75
+    z = torch.randn(n, d) * 1.5
+    wx, wl = torch.randn(n, d), torch.randn(n)
+    x, lp = gen.sample_and_log_prob(n, z=z.to(backend))
+    ((x * wx.to(backend)).sum() + (lp * wl.to(backend)).sum()).backward()
+    gk = torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).cpu()
+    s64 = flow_spec_from_generator(gen, torch.float64)
+    assert s64.kind == "affine"
+    ps = s64.parameters()
+    for p in ps:
+        p.requires_grad_(True)
+    xo, lo = of.sample_and_log_prob(z.double(), s64)
+    ((xo * wx.double()).sum() + (lo * wl.double()).sum()).backward()
+    go = torch.cat([p.grad.reshape(-1) for p in ps])
+    assert (x.detach().cpu() - xo).abs().max() < 1e-4 * max(1.0, float(xo.abs().max()))
+    assert (lp.detach().cpu() - lo).abs().max() < 5e-4
+    assert (gk.double() - go).abs().max() < 2e-3 * go.abs().max()
+    steps = gen.forward_steps(z.to(backend))
+    for a, b in zip(steps, of.flow_forward_steps(z.double(), s64)):
+        assert (a.cpu() - b).abs().max() < 1e-4 * max(1.0, float(b.abs().max()))
