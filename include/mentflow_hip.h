@@ -68,6 +68,11 @@ int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins
                           const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gimage,
                           float* scratch, int64_t scratch_floats, void* stream);
 
+/* Inverse of one layer, x = T^-1(y): the d autoregressive passes of zuko AutoregressiveTransform._inverse
+ * (mentflow/generate/flows/zuko.py:21-22,31-32 -> log_prob / inverse of an arbitrary point).  `order` is required. */
+int mf_flow_rqs_layer_inv(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
+                          const float* y, int64_t n, float* x, void* stream);
+
 /* Affine (MAF) variant: zuko MonotonicAffineTransform, y = x*exp(s~)+t, s~ = s/(1+|s/log(1e-3)|), ladj = s~
  * (mentflow/generate/build.py:28 "maf"; BASELINE config C1).  Same image layout with ONE output block whose slot i of
  * lane half 0 is shift_i and of half 1 is scale_i.                                                             */
@@ -78,6 +83,8 @@ int mf_flow_affine_layer_fwd(const float* image, int d, int hidden_layers, const
 int mf_flow_affine_layer_bwd(const float* image, int d, int hidden_layers, const int32_t* order, const float* x,
                              int64_t n, const float* gy, const float* glogp, float* gx, float* gimage, float* scratch,
                              int64_t scratch_floats, void* stream);
+int mf_flow_affine_layer_inv(const float* image, int d, int hidden_layers, const int32_t* order, const float* y,
+                             int64_t n, float* x, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused linear projection + 1-D Gaussian-KDE histogram over P projections.

@@ -33,6 +33,8 @@ PROTOTYPES = {
     "mf_flow_bwd_scratch_floats": (_i64, [_i64, _i32, _i32]),
     "mf_flow_rqs_layer_fwd": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32, _ptr]),
     "mf_flow_rqs_layer_bwd": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
+    "mf_flow_rqs_layer_inv": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr]),
+    "mf_flow_affine_layer_inv": (_i32, [_ptr, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr]),
     "mf_flow_affine_image_floats": (_i64, [_i32, _i32]),
     "mf_flow_affine_bwd_scratch_floats": (_i64, [_i64, _i32]),
     "mf_flow_affine_layer_fwd": (_i32, [_ptr, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32, _ptr]),

@@ -196,9 +196,10 @@ __device__ __forceinline__ float soft_clip_grad(float v, float a) {
 // Rational-quadratic spline of one feature, evaluated cooperatively by the two lanes (col, col+32) of a particle.
 // v[32]: this lane's slots of the conditioner output (half 0: K widths, then derivatives 0..KD0-1;
 //        half 1: K heights, then derivatives KD0..K-2).  zuko MonotonicRQSTransform.
-// BWD: also returns g[32] = dL/dv (same slot layout) and gx = dL/dx (direct path) for upstream gy = dL/dy,
-//      gl = dL/dladj.
-template <int K, bool BWD>
+// MODE 0: forward (y, ladj).  MODE 1: forward + adjoint: also returns g[32] = dL/dv (same slot layout) and
+// gx = dL/dx (direct path) for upstream gy = dL/dy, gl = dL/dladj.  MODE 2: inverse — `x` is the transformed value,
+// the bin search runs on the heights (half 1) and y_out returns the pre-image (zuko MonotonicRQSTransform._inverse).
+template <int K, int MODE>
 __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh, float& y_out, float& ladj_out,
                                           float gy, float gl, float (&g)[32], float& gx_out) {
     constexpr int KD0 = K / 2;            // derivatives owned by half 0 (interior knots 1..KD0)
@@ -231,7 +232,11 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
         cj[j + 1] = (float)c;
         cnt += (cj[j + 1] < xc) ? 1 : 0;
     }
-    cnt = __shfl_xor(cnt, 32) * hh + cnt * (1 - hh);          // the count of half 0 (widths) for both lanes
+    {   // both lanes use the count of the half that owns the searched knots: widths (half 0), heights for the inverse
+        const int other = __shfl_xor(cnt, 32);
+        const bool mine = (MODE == 2) ? (hh == 1) : (hh == 0);
+        cnt = mine ? cnt : other;
+    }
     const int k = cnt - 1;
     const bool inrange = (cnt >= 1) && (cnt <= K);
     float ck = 0.0f, ck1 = 1.0f;
@@ -266,6 +271,17 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
     const float iw = fast_rcp(w);
     const float hgt = y1 - y0;
     const float s = hgt * iw;
+    if (MODE == 2) {
+        const float yb = x - y0;
+        const float bet = d0 + d1 - 2.0f * s;
+        const float qa = hgt * (s - d0) + yb * bet;
+        const float qb = hgt * d0 - yb * bet;
+        const float qc = -s * yb;
+        const float zi = 2.0f * qc / (-qb - sqrtf(qb * qb - 4.0f * qa * qc));
+        y_out = inrange ? fmaf(zi, w, x0) : x;
+        ladj_out = 0.0f;
+        return;
+    }
     const float z = (x - x0) * iw;
     const float omz = 1.0f - z;
     const float z1 = z * omz;
@@ -279,7 +295,7 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
     y_out = inrange ? fmaf(hgt, R, y0) : x;
     ladj_out = inrange ? logf(jac) : 0.0f;
 
-    if (BWD) {
+    if (MODE == 1) {
         const float tz = 1.0f - 2.0f * z;
         const float num_z = 2.0f * s * z + d0 * tz;
         const float den_z = beta * tz;
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __res
             float v[32], gdummy[32];
             block_linear(lds + g.offW3 + i * HID * WS, lds + g.offB3 + i * HID, h, v, col, hh, sp.kend3[i]);
             float yi, li, gxd;
-            rqs_apply<K, false>(v, xp[i], hh, yi, li, 0.0f, 0.0f, gdummy, gxd);
+            rqs_apply<K, 0>(v, xp[i], hh, yi, li, 0.0f, 0.0f, gdummy, gxd);
             ladj += li;
             if (valid && hh == 0) y[p * d + i] = yi;
         }
@@ -464,7 +480,7 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
             block_linear(W3, lds + g.offB3 + i * HID, h[L - 1], v, col, hh, sp.kend3[i]);
             const float gyi = valid ? gy[pc * d + i] : 0.0f;
             float yi, li, gxd;
-            rqs_apply<K, true>(v, xp[i], hh, yi, li, gyi, gl, gv, gxd);
+            rqs_apply<K, 1>(v, xp[i], hh, yi, li, gyi, gl, gv, gxd);
             // direct path dL/dx_i goes into row i of the dL/dx accumulator tile (row = 4*hh + reg for rows < 8)
 #pragma unroll
             for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
@@ -524,6 +540,98 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
                     if (4 * hh + j < d) gx[p * d + 4 * hh + j] = gacc[j];
             }
         }
+    }
+}
+
+// =========================================================================================== inverse (density of a point)
+// x = T^-1(y) for one autoregressive layer (zuko AutoregressiveTransform._inverse: "x = 0; repeat d times
+// x = meta(x).inv(y)").  Feature of order t only depends on features of order < t, so the d passes are done in order:
+// pass t recomputes the conditioner on the current x^ and inverts the single feature of order t (identical values to
+// zuko's d full passes).  x^ lives in a per-wave LDS strip so that it can be re-read as MFMA B operands.
+struct InvOrder {
+    int feat[FLOW_DMAX + 1];    // feat[t] = feature whose order is t
+};
+
+#ifdef MF_EMU
+#define MF_WAVE_SYNC() emu::wave_sync()
+#else
+#define MF_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
+constexpr int INV_BLOCK = 512;
+template <int K, int L>     // K > 0: rational-quadratic spline;  K == 0: affine
+__global__ __launch_bounds__(INV_BLOCK) void layer_inv_kernel(const float* __restrict__ image, int d,
+                                                              const float* __restrict__ y, int64_t n,
+                                                              float* __restrict__ x, Sparsity sp, InvOrder io) {
+    MF_DYN_SMEM(float, lds);
+    const int nblk = (K > 0) ? d : 1;
+    const ImageLayout g = image_layout(d, L, nblk);
+    stage_image<INV_BLOCK>(lds, image, g.total);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+    float* xs = lds + g.total + wid * (32 * 8) + col * 8;        // this particle's x^[0..7]
+    const int64_t ntiles = (n + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * (INV_BLOCK / 64) + wid; tile < ntiles;
+         tile += (int64_t)gridDim.x * (INV_BLOCK / 64)) {
+        MF_NO_HOIST();
+        const int64_t p = tile * 32 + col;
+        const bool valid = p < n;
+        const float* yp = y + (valid ? p : n - 1) * d;
+        if (hh == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xs[j] = 0.0f;
+        }
+        MF_WAVE_SYNC();
+        for (int t = 0; t < d; ++t) {
+            MF_NO_HOIST();
+            const int i = io.feat[t];
+            const int blk = (K > 0) ? i : 0;
+            float v[32];
+            const bool pure_bias = (K > 0) && (sp.kend3[i] == 0);
+            if (pure_bias) {
+#pragma unroll
+                for (int m = 0; m < 32; ++m) v[m] = lds[g.offB3 + blk * HID + 32 * (m >> 4) + rowmap(m & 15, hh)];
+            } else {
+                float xb[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xb[s] = (2 * s + hh < d) ? xs[2 * s + hh] : 0.0f;
+                f32x16_t h[2];
+                input_layer(lds + g.offW0, lds + g.offB0, g.S0, d, xb, h, col, hh);
+#pragma unroll
+                for (int l = 1; l < L; ++l) {
+                    f32x16_t tt[2];
+                    const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
+                    linear64(W, W + HID * WS, h, tt, col, hh, sp.kend_h[0], sp.kend_h[1]);
+                    relu2(tt);
+                    h[0] = tt[0];
+                    h[1] = tt[1];
+                }
+                f32x16_t phi[2];
+                linear64(lds + g.offW3 + blk * HID * WS, lds + g.offB3 + blk * HID, h, phi, col, hh, sp.kend3[blk],
+                         (K > 0) ? sp.kend3[blk] : 0);
+#pragma unroll
+                for (int m = 0; m < 32; ++m) v[m] = phi[m >> 4][m & 15];
+            }
+            float xi;
+            if (K > 0) {
+                float li, gxd, gdummy[32];
+                rqs_apply<(K > 0 ? K : 8), 2>(v, yp[i], hh, xi, li, 0.0f, 0.0f, gdummy, gxd);
+            } else {
+                // slot i of half 0 = shift_i, of half 1 = scale_i (runtime i: select among the 8 candidate slots)
+                float mine = 0.0f;
+#pragma unroll
+                for (int j = 0; j < FLOW_DMAX + 1; ++j) mine = (j == i) ? v[j] : mine;
+                const float other = __shfl_xor(mine, 32);
+                const float shift = hh ? other : mine, scale = hh ? mine : other;
+                xi = (yp[i] - shift) * fast_exp(-soft_clip(scale, LOG_SLOPE_INV));
+            }
+            MF_WAVE_SYNC();
+            if (hh == 0) xs[i] = xi;
+            MF_WAVE_SYNC();
+        }
+        if (valid && hh == 0) {
+            for (int j = 0; j < d; ++j) x[p * d + j] = xs[j];
+        }
+        MF_WAVE_SYNC();
     }
 }
 
@@ -983,4 +1091,56 @@ extern "C" int mf_flow_affine_layer_bwd(const float* image, int d, int hidden_la
     MF_LAUNCH(outer_accum_kernel, dim3((unsigned)G, 2), 64 * hidden_layers, 0, stream, (const float*)scratch, x, n, d,
               hidden_layers, 1, gimage, sp);
     return check_launch("mf_flow_affine_layer_bwd(outer_accum)");
+}
+
+// ------------------------------------------------------------------------------------------------ inverse C ABI
+static int inv_order(int d, const int32_t* order, InvOrder* io) {
+    if (order == nullptr) return fail("the inverse needs the autoregressive order of the layer");
+    for (int t = 0; t <= FLOW_DMAX; ++t) io->feat[t] = 0;
+    for (int i = 0; i < d; ++i) {
+        if (order[i] < 0 || order[i] >= d) return fail("order[%d] = %d out of range", i, order[i]);
+        io->feat[order[i]] = i;
+    }
+    return 0;
+}
+
+extern "C" int mf_flow_rqs_layer_inv(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
+                                      const float* y, int64_t n, float* x, void* stream) {
+    if (flow_check(d, hidden_layers, n)) return 1;
+    InvOrder io;
+    if (inv_order(d, order, &io)) return 1;
+    if (n == 0) return 0;
+    const Sparsity sp = make_sparsity(d, order, d);
+    const size_t smem = sizeof(float) * ((size_t)image_layout(d, hidden_layers, d).total + (INV_BLOCK / 64) * 32 * 8);
+#define X(KK, LL)                                                                                                     \
+    if (bins == KK && hidden_layers == LL) {                                                                          \
+        MF_ALLOW_DYN_SMEM((layer_inv_kernel<KK, LL>), smem);                                                          \
+        MF_LAUNCH((layer_inv_kernel<KK, LL>), flow_grid(n, INV_BLOCK / 64), INV_BLOCK, smem, stream, image, d, y, n, x,  \
+                  sp, io);                                                                                            \
+        return check_launch("mf_flow_rqs_layer_inv");                                                                 \
+    }
+    MF_RQS_CASES(X)
+#undef X
+    return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: bins in {8,20}, hidden_layers in {2,3})", bins,
+                hidden_layers);
+}
+
+extern "C" int mf_flow_affine_layer_inv(const float* image, int d, int hidden_layers, const int32_t* order, const float* y,
+                                         int64_t n, float* x, void* stream) {
+    if (flow_check(d, hidden_layers, n)) return 1;
+    InvOrder io;
+    if (inv_order(d, order, &io)) return 1;
+    if (n == 0) return 0;
+    const Sparsity sp = make_sparsity(d, order, 1);
+    const size_t smem = sizeof(float) * ((size_t)image_layout(d, hidden_layers, 1).total + (INV_BLOCK / 64) * 32 * 8);
+#define X(LL)                                                                                                         \
+    if (hidden_layers == LL) {                                                                                        \
+        MF_ALLOW_DYN_SMEM((layer_inv_kernel<0, LL>), smem);                                                           \
+        MF_LAUNCH((layer_inv_kernel<0, LL>), flow_grid(n, INV_BLOCK / 64), INV_BLOCK, smem, stream, image, d, y, n, x, sp, \
+                  io);                                                                                                \
+        return check_launch("mf_flow_affine_layer_inv");                                                              \
+    }
+    MF_AFFINE_CASES(X)
+#undef X
+    return fail("no affine kernel instance for hidden_layers=%d (built: 2, 3)", hidden_layers);
 }

@@ -239,6 +239,10 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ 2-D backward
+// A workgroup owns KDE2D_BWD_NPT * 256 particles and walks the projection groups once: the gS images of a group are
+// staged into LDS one time per workgroup (not once per 256 particles), every thread adds the group's contribution to
+// the gx rows of its own particles (thread-private read-modify-write, no atomics).
+constexpr int KDE2D_BWD_NPT = 16;
 __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V0, const float* __restrict__ V1, int P,
     int Pg, const float* __restrict__ coords_x, int Bx, float inv_sx, int Rx, const float* __restrict__ coords_y,
@@ -255,12 +259,7 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
     __syncthreads();
     const float cx0 = cxl[0], inv_dx = 1.0f / (cxl[1] - cxl[0]);
     const float cy0 = cyl[0], inv_dy = 1.0f / (cyl[1] - cyl[0]);
-    const int64_t p = (int64_t)blockIdx.x * KDE_BLOCK + threadIdx.x;
-    const bool valid = p < n;
-    float xv[KDE_DMAX], gv[KDE_DMAX];
-    load_row(x, valid ? p : 0, d, xv);
-#pragma unroll
-    for (int j = 0; j < KDE_DMAX; ++j) gv[j] = 0.0f;
+    const int64_t base = (int64_t)blockIdx.x * KDE_BLOCK * KDE2D_BWD_NPT + threadIdx.x;
     for (int p_begin = 0; p_begin < P; p_begin += Pg) {
         const int np = min(Pg, P - p_begin);
         __syncthreads();
@@ -270,54 +269,61 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
             V1l[i] = V1[p_begin * d + i];
         }
         __syncthreads();
-        for (int q = 0; q < np; ++q) {
-            const float u0 = project(xv, V0l + q * d, d);
-            const float u1 = project(xv, V1l + q * d, d);
-            const int ka = centre_bin(u0, cx0, inv_dx, Bx, Rx);
-            const int kb = centre_bin(u1, cy0, inv_dy, By, Ry);
-            float wy[2 * KDE_RMAX2D + 1], dy[2 * KDE_RMAX2D + 1];
+        for (int t = 0; t < KDE2D_BWD_NPT; ++t) {
+            const int64_t p = base + (int64_t)t * KDE_BLOCK;
+            if (p >= n) break;
+            float xv[KDE_DMAX], gv[KDE_DMAX];
+            load_row(x, p, d, xv);
 #pragma unroll
-            for (int j = 0; j < 2 * KDE_RMAX2D + 1; ++j) {
-                const int b = kb - Ry + j;
-                float w = 0.0f, dw = 0.0f;
-                if (j <= 2 * Ry && b >= 0 && b < By) {
-                    const float r = (u1 - cyl[b]) * inv_sy;
-                    w = gauss_weight(r);
-                    dw = -r * inv_sy * w;
-                }
-                wy[j] = w;
-                dy[j] = dw;
-            }
-            float du0 = 0.0f, du1 = 0.0f;
-            for (int i = 0; i <= 2 * Rx; ++i) {
-                const int a = ka - Rx + i;
-                if (a < 0 || a >= Bx) continue;
-                const float r = (u0 - cxl[a]) * inv_sx;
-                const float wx = gauss_weight(r);
-                const float dwx = -r * inv_sx * wx;
-                const float* row = img + q * BB + a * By;
-                float sa = 0.0f, sb = 0.0f;
+            for (int j = 0; j < KDE_DMAX; ++j) gv[j] = 0.0f;
+            for (int q = 0; q < np; ++q) {
+                const float u0 = project(xv, V0l + q * d, d);
+                const float u1 = project(xv, V1l + q * d, d);
+                const int ka = centre_bin(u0, cx0, inv_dx, Bx, Rx);
+                const int kb = centre_bin(u1, cy0, inv_dy, By, Ry);
+                float wy[2 * KDE_RMAX2D + 1], dy[2 * KDE_RMAX2D + 1];
 #pragma unroll
                 for (int j = 0; j < 2 * KDE_RMAX2D + 1; ++j) {
                     const int b = kb - Ry + j;
+                    float w = 0.0f, dw = 0.0f;
                     if (j <= 2 * Ry && b >= 0 && b < By) {
-                        const float g = row[b];
-                        sa = fmaf(g, wy[j], sa);
-                        sb = fmaf(g, dy[j], sb);
+                        const float r = (u1 - cyl[b]) * inv_sy;
+                        w = gauss_weight(r);
+                        dw = -r * inv_sy * w;
                     }
+                    wy[j] = w;
+                    dy[j] = dw;
                 }
-                du0 = fmaf(dwx, sa, du0);
-                du1 = fmaf(wx, sb, du1);
+                float du0 = 0.0f, du1 = 0.0f;
+                for (int i = 0; i <= 2 * Rx; ++i) {
+                    const int a = ka - Rx + i;
+                    if (a < 0 || a >= Bx) continue;
+                    const float r = (u0 - cxl[a]) * inv_sx;
+                    const float wx = gauss_weight(r);
+                    const float dwx = -r * inv_sx * wx;
+                    const float* row = img + q * BB + a * By;
+                    float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 2 * KDE_RMAX2D + 1; ++j) {
+                        const int b = kb - Ry + j;
+                        if (j <= 2 * Ry && b >= 0 && b < By) {
+                            const float g = row[b];
+                            sa = fmaf(g, wy[j], sa);
+                            sb = fmaf(g, dy[j], sb);
+                        }
+                    }
+                    du0 = fmaf(dwx, sa, du0);
+                    du1 = fmaf(wx, sb, du1);
+                }
+#pragma unroll
+                for (int j = 0; j < KDE_DMAX; ++j)
+                    if (j < d) gv[j] = fmaf(du0, V0l[q * d + j], fmaf(du1, V1l[q * d + j], gv[j]));
             }
+            const bool add = accumulate || p_begin > 0;
 #pragma unroll
             for (int j = 0; j < KDE_DMAX; ++j)
-                if (j < d) gv[j] = fmaf(du0, V0l[q * d + j], fmaf(du1, V1l[q * d + j], gv[j]));
+                if (j < d) gx[p * d + j] = add ? gx[p * d + j] + gv[j] : gv[j];
         }
-    }
-    if (valid) {
-#pragma unroll
-        for (int j = 0; j < KDE_DMAX; ++j)
-            if (j < d) gx[p * d + j] = accumulate ? gx[p * d + j] + gv[j] : gv[j];
     }
 }
 
@@ -654,7 +660,8 @@ extern "C" int mf_proj_kde2d_bwd(const float* x, int64_t n, int d, const float* 
     size_t smem;
     if (kde2d_geometry(d, P, Bx, By, radius_x, radius_y, &Pg, &smem, 0)) return 1;
     if (n == 0) return 0;
-    const int64_t G = (n + KDE_BLOCK - 1) / KDE_BLOCK;
+    const int64_t per_wg = (int64_t)KDE_BLOCK * KDE2D_BWD_NPT;
+    const int64_t G = (n + per_wg - 1) / per_wg;
     ProfScope prof(PK_KDE2D_BWD, stream);
     MF_ALLOW_DYN_SMEM(proj_kde2d_bwd_kernel, smem);
     MF_LAUNCH(proj_kde2d_bwd_kernel, dim3((unsigned)G), KDE_BLOCK, smem, stream, x, n, d, V0, V1, P, Pg, coords_x, Bx,

@@ -169,12 +169,18 @@ class AutoregressiveFlow(GenerativeModel):
             xs, _ = ops.flow_layers_forward(z.clone(), self.flat_parameters(), self.spec())
         return xs
 
-    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("density of an arbitrary point needs the d-pass autoregressive inversion "
-                                  "(SURVEY.md §8f-3, 'next' tier): not built yet")
-
     def inverse(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("autoregressive inversion (SURVEY.md §8f-3, 'next' tier): not built yet")
+        """z = F^-1(x) (flows/zuko.py:31-32): layers in reverse, d autoregressive passes each.  No autograd."""
+        with torch.no_grad():
+            return ops.flow_layers_inverse(x, self.flat_parameters(), self.spec())[-1]
 
     def inverse_steps(self, x: torch.Tensor) -> List[torch.Tensor]:
-        raise NotImplementedError("autoregressive inversion (SURVEY.md §8f-3, 'next' tier): not built yet")
+        with torch.no_grad():
+            return ops.flow_layers_inverse(x.clone(), self.flat_parameters(), self.spec())
+
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        """Density of arbitrary points (flows/zuko.py:21-22): z = F^-1(x), log_prob = logN(z) - ladj_F(z).
+        Evaluation only (notebooks, eval): no autograd graph is recorded."""
+        with torch.no_grad():
+            z = ops.flow_layers_inverse(x, self.flat_parameters(), self.spec())[-1]
+            return ops.flow_layers_forward(z, self.flat_parameters(), self.spec())[1]

@@ -144,6 +144,24 @@ def flow_layers_forward(z: torch.Tensor, flat: torch.Tensor, spec: FlowSpec) -> 
     return xs, logp
 
 
+def flow_layers_inverse(x: torch.Tensor, flat: torch.Tensor, spec: FlowSpec) -> List[torch.Tensor]:
+    """No-grad: [x, T_T^-1(x), ..., z] — the layers in reverse, d autoregressive passes each
+    (mentflow/generate/flows/zuko.py:31-32,43-50)."""
+    x = _f32c(x)
+    images = pack_images(spec, _f32c(flat.detach()))
+    zs = [x]
+    for t in reversed(range(spec.T)):
+        out = torch.empty_like(x)
+        if spec.kind == "rqs":
+            call("mf_flow_rqs_layer_inv", ptr(images[t]), spec.d, spec.L, spec.bins, spec.orders[t], ptr(zs[-1]),
+                 x.shape[0], ptr(out), stream_ptr(x))
+        else:
+            call("mf_flow_affine_layer_inv", ptr(images[t]), spec.d, spec.L, spec.orders[t], ptr(zs[-1]), x.shape[0],
+                 ptr(out), stream_ptr(x))
+        zs.append(out)
+    return zs
+
+
 # ------------------------------------------------------------------------------------------------ projections + KDE
 class ProjKde1dFn(torch.autograd.Function):
     """x[N,d], V[P,d] -> S[P,B] = sum_n exp(-((x_n.V_p - c_k)/sigma)^2 / 2)   (raw kernel sums).
