@@ -407,6 +407,125 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __res
     }
 }
 
+// =========================================================================================== forward, RQS, specialised
+// Compile-time specialisation for a known feature count D and layer direction (REV = 0: order = 0..D-1, 1: reversed):
+// every k-step bound is a constant, so the whole tile is ONE basic block, and the per-feature work is software
+// pipelined — the MFMAs of output block i+1 are issued between the VALU instructions of the spline of feature i
+// (the fp32 MFMA pipe and the VALU co-execute: tools/ubench_mfma_valu.hip), which the generic kernel's wave-uniform
+// branches prevent.
+constexpr int ct_cum(int d, int c) {
+    int n = 0;
+    for (int u = 0; u < HID; ++u) n += ((1 + u % (d - 1)) <= c) ? 1 : 0;
+    return n;
+}
+constexpr int ct_class_of(int d, int j) {
+    int c = 1;
+    while (ct_cum(d, c) <= j) ++c;
+    return c;
+}
+constexpr int ct_kend_h(int d, int rt) { return (ct_cum(d, ct_class_of(d, 32 * rt + 31)) + 1) / 2; }
+constexpr int ct_kend3(int d, int rev, int i) { return (ct_cum(d, rev ? d - 1 - i : i) + 1) / 2; }
+
+template <int KEND0, int KEND1>
+__device__ __forceinline__ void linear64_ct(const float* W, const float* b, const f32x16_t (&in)[2], f32x16_t (&out)[2],
+                                            int col, int hh) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x16_t acc = bias_tile(b, rt, hh);
+        const float* wrow = W + (32 * rt + col) * WS + 4 * hh;
+        constexpr int KE[2] = {KEND0, KEND1};
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
+            if (s < KE[rt]) acc = mfma(wrow[kk], in[s >> 4][s & 15], acc);
+        }
+        out[rt] = acc;
+    }
+}
+
+template <int K, int D, int REV, int I>
+__device__ __forceinline__ void fwd_dims_ct(const float* lds, const ImageLayout& g, const f32x16_t (&h)[2],
+                                            f32x16_t (&phi)[2], const float (&xi)[D], float (&yv)[D], float& ladj, int col,
+                                            int hh) {
+    float v[32], gdummy[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) v[m] = phi[m >> 4][m & 15];
+    constexpr int KN = (I + 1 < D) ? ct_kend3(D, REV, (I + 1 < D) ? I + 1 : I) : 0;
+    if constexpr (I + 1 < D)
+        linear64_ct<KN, KN>(lds + g.offW3 + (I + 1) * HID * WS, lds + g.offB3 + (I + 1) * HID, h, phi, col, hh);
+    float li, gxd;
+    rqs_apply<K, 0>(v, xi[I], hh, yv[I], li, 0.0f, 0.0f, gdummy, gxd);
+    ladj += li;
+    if constexpr (KN > 0) {
+        constexpr int NV = 600 / (2 * KN) > 0 ? 600 / (2 * KN) : 1;
+#pragma unroll
+        for (int q = 0; q < 2 * KN; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA of block I+1
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // its weight fragment (ds_read)
+            __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);     // a slice of the spline's VALU work
+        }
+    }
+    if constexpr (I + 1 < D) fwd_dims_ct<K, D, REV, I + 1>(lds, g, h, phi, xi, yv, ladj, col, hh);
+}
+
+template <int K, int L, int BLOCK, int D, int REV>
+__global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_ct_kernel(const float* __restrict__ image,
+                                                                 const float* __restrict__ x, int64_t n,
+                                                                 float* __restrict__ y, const float* __restrict__ logp_in,
+                                                                 float* __restrict__ logp_out, int init_logp) {
+    MF_DYN_SMEM(float, lds);
+    const ImageLayout g = image_layout(D, L, D);
+    stage_image<BLOCK>(lds, image, g.total);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+    const int64_t ntiles = (n + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (BLOCK / 64)) {
+        MF_NO_HOIST();
+        const int64_t p = tile * 32 + col;
+        const bool valid = p < n;
+        const float* xp = x + (valid ? p : n - 1) * D;
+        float xi[D], yv[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) xi[i] = xp[i];
+        float xb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) t = (2 * s + hh == i) ? xi[i] : t;
+            xb[s] = t;
+        }
+        f32x16_t h[2];
+        input_layer(lds + g.offW0, lds + g.offB0, g.S0, D, xb, h, col, hh);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            f32x16_t t[2];
+            const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
+            linear64_ct<ct_kend_h(D, 0), ct_kend_h(D, 1)>(W, W + HID * WS, h, t, col, hh);
+            relu2(t);
+            h[0] = t[0];
+            h[1] = t[1];
+        }
+        f32x16_t phi[2];
+        linear64_ct<ct_kend3(D, REV, 0), ct_kend3(D, REV, 0)>(lds + g.offW3, lds + g.offB3, h, phi, col, hh);
+        float ladj = 0.0f;
+        fwd_dims_ct<K, D, REV, 0>(lds, g, h, phi, xi, yv, ladj, col, hh);
+        if (valid && hh == 0) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) y[p * D + i] = yv[i];
+            float lp0;
+            if (init_logp) {
+                float q = 0.0f;
+#pragma unroll
+                for (int i = 0; i < D; ++i) q = fmaf(xi[i], xi[i], q);
+                lp0 = -0.5f * q - 0.9189385332046727f * (float)D;
+            } else {
+                lp0 = logp_in[p];
+            }
+            logp_out[p] = lp0 - ladj;
+        }
+    }
+}
+
 // scratch buffers are stored as transposed 32-particle tiles:  X[tile][c][particle]  (64 x 32 floats = 8 KiB per
 // tile), column c = 32*rt + 16*hh + r <-> accumulator register r of row tile rt of lane half hh = MFMA row
 // 32*rt + rowmap(r, hh).  The parameter-gradient contraction (particles = MFMA k) then reads, per lane, 16 consecutive
@@ -976,6 +1095,28 @@ extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layer
     if (n == 0) return 0;
     const Sparsity sp = make_sparsity(d, order, d);
     const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, d).total;
+    // compile-time specialised kernels for the reference configurations (d = 6 or 2, 3 hidden layers, K = 20 bins,
+    // ascending / descending order), unless MENTFLOW_FWD_GENERIC=1
+    static const bool fwd_generic = [] { const char* e = getenv("MENTFLOW_FWD_GENERIC"); return e && atoi(e) == 1; }();
+    if (!fwd_generic && order != nullptr && bins == 20 && hidden_layers == 3 && (d == 6 || d == 2)) {
+        bool asc = true, desc = true;
+        for (int i = 0; i < d; ++i) {
+            asc = asc && order[i] == i;
+            desc = desc && order[i] == d - 1 - i;
+        }
+        if (asc || desc) {
+            ProfScope prof(PK_FLOW_FWD, stream);
+#define XCT(DD, RR)                                                                                                   \
+    if (d == DD && (RR ? desc : asc)) {                                                                               \
+        MF_ALLOW_DYN_SMEM((rqs_layer_fwd_ct_kernel<20, 3, 512, DD, RR>), smem);                                       \
+        MF_LAUNCH((rqs_layer_fwd_ct_kernel<20, 3, 512, DD, RR>), flow_grid(n, 8), 512, smem, stream, image, x, n, y,    \
+                  logp_in, logp_out, init_logp);                                                                      \
+        return check_launch("mf_flow_rqs_layer_fwd(ct)");                                                             \
+    }
+            XCT(6, 0) XCT(6, 1) XCT(2, 0) XCT(2, 1)
+#undef XCT
+        }
+    }
     // 1024-thread workgroups (4 waves per SIMD at <= 128 VGPRs) hide LDS and spline latency better than 512
     static const int fwd_block = [] {
         const char* e = getenv("MENTFLOW_FWD_BLOCK");
