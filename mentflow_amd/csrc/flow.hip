@@ -970,71 +970,61 @@ __global__ __launch_bounds__(64 * OA_MAX_WAVES) void outer_accum_kernel(const fl
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     float bsum0 = 0.0f, bsum1 = 0.0f;
     // lane (col, hh): column 32*t + col, particles 16*hh + s (s = 0..15): k-step s pairs particles (s, 16 + s).
-    // The fragments of the next tile are loaded while the MFMAs of the current one run (register double buffer).
-    auto load_tile = [&](int64_t tile, float4 (&a0)[4], float4 (&a1)[4], float4 (&b0)[4], float4 (&b1)[4]) {
-        const float4* pa0 = reinterpret_cast<const float4*>(A + tile * 2048 + col * 32 + 16 * hh);
-        const float4* pa1 = reinterpret_cast<const float4*>(A + tile * 2048 + (32 + col) * 32 + 16 * hh);
+    // Work is issued in half tiles (8 particles per lane half: eight 16-byte loads, 32 MFMAs) so that the kernel stays
+    // under 128 VGPRs: four waves per SIMD hide the HBM latency better than a deeper per-wave prefetch did.
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const float4* pa0 = reinterpret_cast<const float4*>(A + tile * 2048 + col * 32 + 16 * hh) + 2 * half;
+            const float4* pa1 = reinterpret_cast<const float4*>(A + tile * 2048 + (32 + col) * 32 + 16 * hh) + 2 * half;
+            float4 a0[2], a1[2], b0[2], b1[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            a0[q] = pa0[q];
-            a1[q] = pa1[q];
-        }
-        if (from_x) {
+            for (int q = 0; q < 2; ++q) {
+                a0[q] = pa0[q];
+                a1[q] = pa1[q];
+            }
+            if (from_x) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float t[4];
+                for (int q = 0; q < 2; ++q) {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int64_t p = tile * 32 + 16 * hh + 4 * (2 * half + q) + e;
+                        t[e] = (col < d && p < n) ? x[p * d + col] : 0.0f;
+                    }
+                    b0[q] = make_float4(t[0], t[1], t[2], t[3]);
+                    b1[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            } else {
+                const float4* pb0 = reinterpret_cast<const float4*>(B + tile * 2048 + col * 32 + 16 * hh) + 2 * half;
+                const float4* pb1 = reinterpret_cast<const float4*>(B + tile * 2048 + (32 + col) * 32 + 16 * hh) + 2 * half;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    b0[q] = need_b0 ? pb0[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    b1[q] = need_b1 ? pb1[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float av0[4] = {a0[q].x, a0[q].y, a0[q].z, a0[q].w};
+                const float av1[4] = {a1[q].x, a1[q].y, a1[q].z, a1[q].w};
+                const float bv0[4] = {b0[q].x, b0[q].y, b0[q].z, b0[q].w};
+                const float bv1[4] = {b1[q].x, b1[q].y, b1[q].z, b1[q].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int64_t p = tile * 32 + 16 * hh + 4 * q + e;
-                    t[e] = (col < d && p < n) ? x[p * d + col] : 0.0f;
-                }
-                b0[q] = make_float4(t[0], t[1], t[2], t[3]);
-                b1[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-        } else {
-            const float4* pb0 = reinterpret_cast<const float4*>(B + tile * 2048 + col * 32 + 16 * hh);
-            const float4* pb1 = reinterpret_cast<const float4*>(B + tile * 2048 + (32 + col) * 32 + 16 * hh);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                b0[q] = need_b0 ? pb0[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                b1[q] = need_b1 ? pb1[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-        }
-    };
-    auto compute_tile = [&](const float4 (&a0)[4], const float4 (&a1)[4], const float4 (&b0)[4], const float4 (&b1)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float av0[4] = {a0[q].x, a0[q].y, a0[q].z, a0[q].w};
-            const float av1[4] = {a1[q].x, a1[q].y, a1[q].z, a1[q].w};
-            const float bv0[4] = {b0[q].x, b0[q].y, b0[q].z, b0[q].w};
-            const float bv1[4] = {b1[q].x, b1[q].y, b1[q].z, b1[q].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bsum0 += av0[e];
-                bsum1 += av1[e];
-                if (need_b0) {
-                    acc[0][0] = mfma(av0[e], bv0[e], acc[0][0]);
-                    acc[1][0] = mfma(av1[e], bv0[e], acc[1][0]);
-                }
-                if (need_b1) {
-                    acc[0][1] = mfma(av0[e], bv1[e], acc[0][1]);
-                    acc[1][1] = mfma(av1[e], bv1[e], acc[1][1]);
+                    bsum0 += av0[e];
+                    bsum1 += av1[e];
+                    if (need_b0) {
+                        acc[0][0] = mfma(av0[e], bv0[e], acc[0][0]);
+                        acc[1][0] = mfma(av1[e], bv0[e], acc[1][0]);
+                    }
+                    if (need_b1) {
+                        acc[0][1] = mfma(av0[e], bv1[e], acc[0][1]);
+                        acc[1][1] = mfma(av1[e], bv1[e], acc[1][1]);
+                    }
                 }
             }
         }
-    };
-    float4 ua0[4], ua1[4], ub0[4], ub1[4], va0[4], va1[4], vb0[4], vb1[4];
-    int64_t tile = blockIdx.x;
-    if (tile < ntiles) load_tile(tile, ua0, ua1, ub0, ub1);
-    while (tile < ntiles) {
-        const int64_t t1 = tile + gridDim.x;
-        if (t1 < ntiles) load_tile(t1, va0, va1, vb0, vb1);
-        compute_tile(ua0, ua1, ub0, ub1);
-        if (t1 >= ntiles) break;
-        const int64_t t2 = t1 + gridDim.x;
-        if (t2 < ntiles) load_tile(t2, ua0, ua1, ub0, ub1);
-        compute_tile(va0, va1, vb0, vb1);
-        tile = t2;
     }
     // memory column c = 32*rt + 16*hc + r  <->  image row rho = 32*rt + rowmap(r, hc)
 #pragma unroll
@@ -1166,7 +1156,8 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
                     bins, hidden_layers);
     if (check_launch("mf_flow_rqs_layer_bwd")) return 1;
     const int64_t ntiles = (n + 31) / 32;
-    int64_t G = ntiles < 4 * NUM_CU ? ntiles : 4 * NUM_CU;
+    static const int oa_mult = [] { const char* e = getenv("MENTFLOW_OA_MULT"); return e ? atoi(e) : 2; }();
+    int64_t G = ntiles < oa_mult * NUM_CU ? ntiles : oa_mult * NUM_CU;
     const int nwaves = d > hidden_layers ? d : hidden_layers;
     if (nwaves > OA_MAX_WAVES) return fail("too many linear blocks for the gradient kernel");
     ProfScope prof(PK_OUTER_ACCUM, stream);

@@ -1,0 +1,115 @@
+"""Size-independent properties at BASELINE.json's full per-GPU sizes (GPU only): the oracle cannot run there
+(eager dense autograd needs ~29 GB at N = 100 k, P = 100), so the kernels are checked against invariants."""
+import pytest
+import torch
+
+import mentflow_amd as mf
+from mentflow_amd import ops
+from mentflow_amd.harness import build_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from mentflow_amd import _lib
+    _lib.use_library(_lib.DEFAULT_PATH)
+    return torch.device("cuda", 0)
+
+
+def test_c4_histograms_additive_normalised_and_chunk_invariant(dev):
+    """C4 shapes: d = 6, P = 100, B = 64, 2 097 152 particles."""
+    prob = build_problem(ndim=6, num=100, bins=64, xmax=3.5, seed=0, transforms=5, prior_scale=3.0, device=dev,
+                         dist_name="gaussian_mixture", meas_samples=200_000, penalty_parameter=500.0)
+    diag = prob.diagnostics[0][0]
+    V = torch.stack([t.matrix[0] for t in prob.transforms]).contiguous()
+    n = 2_097_152
+    torch.manual_seed(0)
+    x = torch.randn(n, 6, device=dev) * 1.2
+    R = ops.kde_radius(0.5)
+    S = ops.ProjKde1dFn.apply(x, V, diag.coords, float(diag.bandwidth), R)
+    Sa = ops.ProjKde1dFn.apply(x[: n // 3].contiguous(), V, diag.coords, float(diag.bandwidth), R)
+    Sb = ops.ProjKde1dFn.apply(x[n // 3:].contiguous(), V, diag.coords, float(diag.bandwidth), R)
+    # linearity in the particle set (fixed-point accumulation: exact up to the final fp32 rounding)
+    torch.testing.assert_close(S, Sa + Sb, rtol=3e-7, atol=1e-6)
+    # run-to-run reproducibility of the integer accumulation
+    S2 = ops.ProjKde1dFn.apply(x, V, diag.coords, float(diag.bandwidth), R)
+    assert (S - S2).abs().max() <= 1e-6 * S.abs().max()
+    # mass: every particle inside the range contributes sum_k exp(-2 (t-k)^2) ~ sqrt(pi/2) = 1.2533 (sigma = delta/2)
+    u = x @ V.T
+    inside = ((u > -3.0) & (u < 3.0)).float().sum(0)
+    assert (S.sum(1) >= 1.2533 * inside * 0.999).all() and (S.sum(1) <= 1.2534 * n).all()
+    # normalised prediction integrates to one; histogram of a projection equals the single-projection call
+    ghat, _ = ops.HistNormDiscFn.apply(S, None, True, 1.0 / n, float(diag.resolution), 1e-10, 0, 0.0, 1.0)
+    torch.testing.assert_close((ghat.sum(1) * diag.resolution).cpu(), torch.ones(100), rtol=1e-5, atol=1e-5)
+    one = mf.simulate.forward(x, [prob.transforms[7]], [[diag]])[0][0]
+    torch.testing.assert_close(one, ghat[7], rtol=1e-6, atol=1e-9)
+
+
+def test_c3_flow_roundtrip_logprob_and_chunked_backward(dev):
+    """C3/C4 flow: 6-D NSF 5 x [3 x 64], K = 20; 1 048 576 particles."""
+    torch.manual_seed(0)
+    gen = mf.generate.build_generator("nsf", device=dev, input_features=6, output_features=6, hidden_layers=3,
+                                      hidden_units=64, transforms=5, bins=20)
+    with torch.no_grad():                       # make the conditioner matter (default init is near identity)
+        for layer in gen.layers:
+            lin = layer.linears()[-1]
+            lin.weight.mul_(2.0)
+    n = 1_048_576
+    z = torch.randn(n, 6, device=dev)
+    with torch.no_grad():
+        x, lp = gen.sample_and_log_prob(n, z=z)
+    assert torch.isfinite(x).all() and torch.isfinite(lp).all()
+    # encode -> decode round trip, and log_prob(x) == log_prob returned with the sample
+    zb = gen.inverse(x)
+    err = (zb - z).abs()
+    assert err.median() < 2e-6 and err.quantile(0.999) < 1e-3
+    lp2 = gen.log_prob(x)
+    dl = (lp2 - lp).abs()
+    assert dl.median() < 2e-5 and dl.quantile(0.999) < 5e-3
+    # log-density normalisation proxy: E_z[exp(-ladj)] is finite and ladj has the right sign convention:
+    # logp = logN(z) - ladj  =>  ladj = logN(z) - logp
+    ladj = (-0.5 * (z ** 2).sum(1) - 3 * 1.8378770664093453) - lp
+    assert torch.isfinite(ladj).all()
+    # backward: chunk size must not change the gradients (scratch reuse, tile padding, atomics)
+    w = torch.randn(n, 6, device=dev)
+    grads = []
+    for chunk in (1 << 19, 100_003):
+        gen.spec().bwd_chunk = chunk
+        gen.zero_grad()
+        xx, ll = gen.sample_and_log_prob(n, z=z)
+        ((xx * w).sum() / n + ll.mean()).backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).clone())
+    gen.spec().bwd_chunk = 1 << 19
+    torch.testing.assert_close(grads[0], grads[1], rtol=2e-4, atol=2e-5 * float(grads[0].abs().max()))
+    # linearity of the backward in the upstream gradient
+    gen.zero_grad()
+    xx, ll = gen.sample_and_log_prob(n, z=z)
+    (2.0 * ((xx * w).sum() / n + ll.mean())).backward()
+    g2 = torch.cat([p.grad.reshape(-1) for p in gen.parameters()])
+    torch.testing.assert_close(g2, 2.0 * grads[0], rtol=2e-4, atol=4e-5 * float(grads[0].abs().max()))
+
+
+def test_c5_2d_histograms_additive(dev):
+    """C5 shapes: 100 two-dimensional projections, 85 x 85 bins."""
+    from mentflow_amd.harness import make_transforms_nd_2d_random
+    tfs = [t.to(dev) for t in make_transforms_nd_2d_random(100, 6, 0)]
+    e = torch.linspace(-3.5, 3.5, 86)
+    diag = mf.diagnostics.Histogram2D(axis=(0, 2), edges=(e, e), bandwidth=(0.5, 0.5)).to(dev)
+    V0 = torch.stack([t.matrix[0] for t in tfs]).contiguous()
+    V1 = torch.stack([t.matrix[2] for t in tfs]).contiguous()
+    n = 262_144
+    torch.manual_seed(1)
+    x = torch.randn(n, 6, device=dev)
+    args = (diag.coords_x, diag.coords_y, float(diag.bandwidth_x), float(diag.bandwidth_y), 4, 4)
+    S = ops.ProjKde2dFn.apply(x, V0, V1, *args)
+    Sa = ops.ProjKde2dFn.apply(x[: n // 2].contiguous(), V0, V1, *args)
+    Sb = ops.ProjKde2dFn.apply(x[n // 2:].contiguous(), V0, V1, *args)
+    torch.testing.assert_close(S, Sa + Sb, rtol=3e-7, atol=1e-6)
+    # marginalising the 2-D kernel sums over one axis gives (1-D sums) x (mass of the other kernel ~ 1.2533)
+    S1 = ops.ProjKde1dFn.apply(x, V0, diag.coords_x, float(diag.bandwidth_x), 4)
+    u1 = x @ V1.T
+    inside = (u1.abs() < 3.0).all(0)
+    ratio = S.sum(2)[inside] / S1[inside].clamp_min(1e-3)
+    big = S1[inside] > 100.0
+    assert ((ratio[big] - 1.2533).abs() < 5e-3).all()
