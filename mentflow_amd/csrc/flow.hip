@@ -99,6 +99,9 @@ static Sparsity make_sparsity(int d, const int32_t* order, int nblk) {
 // weight-fragment loads of every layer out of the particle-tile loop and then spills them (104 VGPRs spilled in the
 // forward kernel).  A compiler-only memory barrier at the top of each tile keeps the loads next to their MFMAs.
 #define MF_NO_HOIST() asm volatile("" ::: "memory")
+#ifndef MF_ROTATE_DIMS
+#define MF_ROTATE_DIMS 0      // measured: rotating the feature order per wave does not help (5.3 -> 5.7 ms forward)
+#endif
 
 __device__ __forceinline__ f32x16_t mfma(float a, float b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -120,7 +123,9 @@ __device__ __forceinline__ f32x16_t bias_tile(const float* b, int rt, int hh) {
 }
 
 // out[2] = W[64 x 64] * in[2]  (+ bias), weights natural [out][in] with stride WS
-// k-steps [0, kend0) for output tile 0 and [0, kend1) for tile 1 (wave-uniform bounds: masked-out blocks skipped)
+// k-steps [0, kend0) for output tile 0 and [0, kend1) for tile 1 (wave-uniform bounds: masked-out blocks skipped).
+// Steps are issued in groups of four under ONE branch, so that the four weight-fragment ds_reads are in flight together
+// instead of one exposed LDS round trip per MFMA (bounds are rounded to the group: the extra steps multiply zeros).
 __device__ __forceinline__ void linear64(const float* W, const float* b, const f32x16_t (&in)[2], f32x16_t (&out)[2],
                                          int col, int hh, int kend0, int kend1) {
 #pragma unroll
@@ -129,16 +134,21 @@ __device__ __forceinline__ void linear64(const float* W, const float* b, const f
         const float* wrow = W + (32 * rt + col) * WS + 4 * hh;
         const int kend = rt ? kend1 : kend0;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
-            if (s < kend) acc = mfma(wrow[kk], in[s >> 4][s & 15], acc);
+        for (int s4 = 0; s4 < 32; s4 += 4) {
+            if (s4 < kend) {
+                float a[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = wrow[32 * ((s4 + j) >> 4) + rowmap((s4 + j) & 15, 0)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = mfma(a[j], in[(s4 + j) >> 4][(s4 + j) & 15], acc);
+            }
         }
         out[rt] = acc;
     }
 }
 
 // out[2] += W^T * in[2]   (out rows = input units of W, contraction over W's output units)
-// k-steps [kbeg0, 32) for output tile 0 and [kbeg1, 32) for tile 1
+// k-steps [kbeg0, 32) for output tile 0 and [kbeg1, 32) for tile 1 (rounded down to a group of four)
 __device__ __forceinline__ void linear64_t(const float* W, const f32x16_t (&in)[2], f32x16_t (&out)[2], int col, int hh,
                                            int kbeg0, int kbeg1) {
 #pragma unroll
@@ -147,9 +157,14 @@ __device__ __forceinline__ void linear64_t(const float* W, const f32x16_t (&in)[
         const float* wcol = W + 4 * hh * WS + 32 * rt + col;
         const int kbeg = rt ? kbeg1 : kbeg0;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
-            if (s >= kbeg) acc = mfma(wcol[kk * WS], in[s >> 4][s & 15], acc);
+        for (int s4 = 0; s4 < 32; s4 += 4) {
+            if (s4 + 4 > kbeg) {
+                float a[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = wcol[(32 * ((s4 + j) >> 4) + rowmap((s4 + j) & 15, 0)) * WS];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = mfma(a[j], in[(s4 + j) >> 4][(s4 + j) & 15], acc);
+            }
         }
         out[rt] = acc;
     }
@@ -391,8 +406,12 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __res
             h[1] = t[1];
         }
         float ladj = 0.0f;
+        // waves walk the features in rotated order so that the waves sharing a SIMD are not all in the same
+        // (MFMA-heavy or VALU-heavy) phase at the same time
+        const int rot = MF_ROTATE_DIMS ? wid % d : 0;
 #pragma unroll 1
-        for (int i = 0; i < d; ++i) {
+        for (int ii = 0; ii < d; ++ii) {
+            const int i = (ii + rot >= d) ? ii + rot - d : ii + rot;
             float v[32], gdummy[32];
             block_linear(lds + g.offW3 + i * HID * WS, lds + g.offB3 + i * HID, h, v, col, hh, sp.kend3[i]);
             float yi, li, gxd;
@@ -402,125 +421,6 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __res
         }
         if (valid && hh == 0) {
             const float lp0 = init_logp ? base_log_prob(xp, d) : logp_in[p];
-            logp_out[p] = lp0 - ladj;
-        }
-    }
-}
-
-// =========================================================================================== forward, RQS, specialised
-// Compile-time specialisation for a known feature count D and layer direction (REV = 0: order = 0..D-1, 1: reversed):
-// every k-step bound is a constant, so the whole tile is ONE basic block, and the per-feature work is software
-// pipelined — the MFMAs of output block i+1 are issued between the VALU instructions of the spline of feature i
-// (the fp32 MFMA pipe and the VALU co-execute: tools/ubench_mfma_valu.hip), which the generic kernel's wave-uniform
-// branches prevent.
-constexpr int ct_cum(int d, int c) {
-    int n = 0;
-    for (int u = 0; u < HID; ++u) n += ((1 + u % (d - 1)) <= c) ? 1 : 0;
-    return n;
-}
-constexpr int ct_class_of(int d, int j) {
-    int c = 1;
-    while (ct_cum(d, c) <= j) ++c;
-    return c;
-}
-constexpr int ct_kend_h(int d, int rt) { return (ct_cum(d, ct_class_of(d, 32 * rt + 31)) + 1) / 2; }
-constexpr int ct_kend3(int d, int rev, int i) { return (ct_cum(d, rev ? d - 1 - i : i) + 1) / 2; }
-
-template <int KEND0, int KEND1>
-__device__ __forceinline__ void linear64_ct(const float* W, const float* b, const f32x16_t (&in)[2], f32x16_t (&out)[2],
-                                            int col, int hh) {
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        f32x16_t acc = bias_tile(b, rt, hh);
-        const float* wrow = W + (32 * rt + col) * WS + 4 * hh;
-        constexpr int KE[2] = {KEND0, KEND1};
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
-            if (s < KE[rt]) acc = mfma(wrow[kk], in[s >> 4][s & 15], acc);
-        }
-        out[rt] = acc;
-    }
-}
-
-template <int K, int D, int REV, int I>
-__device__ __forceinline__ void fwd_dims_ct(const float* lds, const ImageLayout& g, const f32x16_t (&h)[2],
-                                            f32x16_t (&phi)[2], const float (&xi)[D], float (&yv)[D], float& ladj, int col,
-                                            int hh) {
-    float v[32], gdummy[32];
-#pragma unroll
-    for (int m = 0; m < 32; ++m) v[m] = phi[m >> 4][m & 15];
-    constexpr int KN = (I + 1 < D) ? ct_kend3(D, REV, (I + 1 < D) ? I + 1 : I) : 0;
-    if constexpr (I + 1 < D)
-        linear64_ct<KN, KN>(lds + g.offW3 + (I + 1) * HID * WS, lds + g.offB3 + (I + 1) * HID, h, phi, col, hh);
-    float li, gxd;
-    rqs_apply<K, 0>(v, xi[I], hh, yv[I], li, 0.0f, 0.0f, gdummy, gxd);
-    ladj += li;
-    if constexpr (KN > 0) {
-        constexpr int NV = 600 / (2 * KN) > 0 ? 600 / (2 * KN) : 1;
-#pragma unroll
-        for (int q = 0; q < 2 * KN; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA of block I+1
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // its weight fragment (ds_read)
-            __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);     // a slice of the spline's VALU work
-        }
-    }
-    if constexpr (I + 1 < D) fwd_dims_ct<K, D, REV, I + 1>(lds, g, h, phi, xi, yv, ladj, col, hh);
-}
-
-template <int K, int L, int BLOCK, int D, int REV>
-__global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_ct_kernel(const float* __restrict__ image,
-                                                                 const float* __restrict__ x, int64_t n,
-                                                                 float* __restrict__ y, const float* __restrict__ logp_in,
-                                                                 float* __restrict__ logp_out, int init_logp) {
-    MF_DYN_SMEM(float, lds);
-    const ImageLayout g = image_layout(D, L, D);
-    stage_image<BLOCK>(lds, image, g.total);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
-    const int64_t ntiles = (n + 31) / 32;
-    for (int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (BLOCK / 64)) {
-        MF_NO_HOIST();
-        const int64_t p = tile * 32 + col;
-        const bool valid = p < n;
-        const float* xp = x + (valid ? p : n - 1) * D;
-        float xi[D], yv[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) xi[i] = xp[i];
-        float xb[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float t = 0.0f;
-#pragma unroll
-            for (int i = 0; i < D; ++i) t = (2 * s + hh == i) ? xi[i] : t;
-            xb[s] = t;
-        }
-        f32x16_t h[2];
-        input_layer(lds + g.offW0, lds + g.offB0, g.S0, D, xb, h, col, hh);
-#pragma unroll
-        for (int l = 1; l < L; ++l) {
-            f32x16_t t[2];
-            const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
-            linear64_ct<ct_kend_h(D, 0), ct_kend_h(D, 1)>(W, W + HID * WS, h, t, col, hh);
-            relu2(t);
-            h[0] = t[0];
-            h[1] = t[1];
-        }
-        f32x16_t phi[2];
-        linear64_ct<ct_kend3(D, REV, 0), ct_kend3(D, REV, 0)>(lds + g.offW3, lds + g.offB3, h, phi, col, hh);
-        float ladj = 0.0f;
-        fwd_dims_ct<K, D, REV, 0>(lds, g, h, phi, xi, yv, ladj, col, hh);
-        if (valid && hh == 0) {
-#pragma unroll
-            for (int i = 0; i < D; ++i) y[p * D + i] = yv[i];
-            float lp0;
-            if (init_logp) {
-                float q = 0.0f;
-#pragma unroll
-                for (int i = 0; i < D; ++i) q = fmaf(xi[i], xi[i], q);
-                lp0 = -0.5f * q - 0.9189385332046727f * (float)D;
-            } else {
-                lp0 = logp_in[p];
-            }
             logp_out[p] = lp0 - ladj;
         }
     }
@@ -592,8 +492,10 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
             gacc[r] = 0.0f;
         }
         const float gl = valid ? -glogp[pc] : 0.0f;
+        const int rot = MF_ROTATE_DIMS ? wid % d : 0;
 #pragma unroll 1
-        for (int i = 0; i < d; ++i) {
+        for (int ii = 0; ii < d; ++ii) {
+            const int i = (ii + rot >= d) ? ii + rot - d : ii + rot;
             float v[32], gv[32];
             const float* W3 = lds + g.offW3 + i * HID * WS;
             block_linear(W3, lds + g.offB3 + i * HID, h[L - 1], v, col, hh, sp.kend3[i]);
@@ -613,9 +515,12 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
                     f32x16_t acc = gh[rt];
                     const float* wcol = W3 + 4 * hh * WS + 32 * rt + col;
 #pragma unroll
-                    for (int s = 0; s < 32; ++s) {
-                        const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
-                        acc = mfma(wcol[kk * WS], gv[s], acc);
+                    for (int s4 = 0; s4 < 32; s4 += 4) {
+                        float a[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = wcol[(32 * ((s4 + j) >> 4) + rowmap((s4 + j) & 15, 0)) * WS];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc = mfma(a[j], gv[s4 + j], acc);
                     }
                     gh[rt] = acc;
                 }
@@ -1085,28 +990,6 @@ extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layer
     if (n == 0) return 0;
     const Sparsity sp = make_sparsity(d, order, d);
     const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, d).total;
-    // compile-time specialised kernels for the reference configurations (d = 6 or 2, 3 hidden layers, K = 20 bins,
-    // ascending / descending order), unless MENTFLOW_FWD_GENERIC=1
-    static const bool fwd_generic = [] { const char* e = getenv("MENTFLOW_FWD_GENERIC"); return e && atoi(e) == 1; }();
-    if (!fwd_generic && order != nullptr && bins == 20 && hidden_layers == 3 && (d == 6 || d == 2)) {
-        bool asc = true, desc = true;
-        for (int i = 0; i < d; ++i) {
-            asc = asc && order[i] == i;
-            desc = desc && order[i] == d - 1 - i;
-        }
-        if (asc || desc) {
-            ProfScope prof(PK_FLOW_FWD, stream);
-#define XCT(DD, RR)                                                                                                   \
-    if (d == DD && (RR ? desc : asc)) {                                                                               \
-        MF_ALLOW_DYN_SMEM((rqs_layer_fwd_ct_kernel<20, 3, 512, DD, RR>), smem);                                       \
-        MF_LAUNCH((rqs_layer_fwd_ct_kernel<20, 3, 512, DD, RR>), flow_grid(n, 8), 512, smem, stream, image, x, n, y,    \
-                  logp_in, logp_out, init_logp);                                                                      \
-        return check_launch("mf_flow_rqs_layer_fwd(ct)");                                                             \
-    }
-            XCT(6, 0) XCT(6, 1) XCT(2, 0) XCT(2, 1)
-#undef XCT
-        }
-    }
     // 1024-thread workgroups (4 waves per SIMD at <= 128 VGPRs) hide LDS and spline latency better than 512
     static const int fwd_block = [] {
         const char* e = getenv("MENTFLOW_FWD_BLOCK");

@@ -1,0 +1,68 @@
+"""BASELINE.json configs as parity cases (GPU): C1 at its full size (the reference's own CPU-runnable case: rec_2d/linear
+swissroll, 7 projections, affine "maf" flow, 50 000 particles) and C2/C3/C4 shapes at an oracle-sized batch, each a full
+MENTFlow.loss() + backward against the eager dense oracle on identical weights, measurements and base draw z."""
+import pytest
+import torch
+
+from mentflow_amd.harness import build_problem
+from oracle.harness import oracle_step
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from mentflow_amd import _lib
+    _lib.use_library(_lib.DEFAULT_PATH)
+    return torch.device("cuda", 0)
+
+
+def _check(prob, n, dev, dtype=torch.float32, gtol=2e-3):
+    torch.manual_seed(123)
+    d = prob.cfg["ndim"]
+    z = torch.randn(n, d)
+    prob.model.generator.inject_z = z.to(dev)
+    L, H, D = prob.model.loss(n)
+    L.backward()
+    g = torch.cat([p.grad.reshape(-1) for p in prob.model.parameters()]).cpu()
+    Lo, Ho, Do, go = oracle_step(prob, z, dtype)
+    mu = float(prob.model.penalty_parameter)
+    Dk, Dr = torch.stack(D).detach().cpu(), torch.stack(Do).float()
+    assert abs(float(H.detach()) - float(Ho)) < 2e-5 * max(1.0, abs(float(Ho)))
+    assert (Dk - Dr).abs().max() < 2e-6 + 2e-4 * float(Dr.abs().max())
+    assert abs(float(L.detach()) - float(Lo)) < 1e-4 + mu * 2e-6 + 1e-5 * abs(float(Lo))
+    assert (g.double() - go.double()).abs().max() < gtol * float(go.abs().max())
+    return float(L.detach()), float(Lo)
+
+
+def test_c1_full_size_affine_swissroll(dev):
+    prob = build_problem(ndim=2, num=7, bins=85, xmax=3.5, seed=21, transforms=5, prior_scale=1.0, device=dev,
+                         dist_name="swissroll", optics="2d_linear", gen_name="maf", meas_samples=1_000_000,
+                         penalty_parameter=500.0)
+    _check(prob, 50_000, dev)
+
+
+def test_c2_shape_nsf_swissroll(dev):
+    prob = build_problem(ndim=2, num=7, bins=85, xmax=3.5, seed=21, transforms=5, prior_scale=1.0, device=dev,
+                         dist_name="swissroll", optics="2d_linear", gen_name="nsf", meas_samples=1_000_000,
+                         penalty_parameter=500.0)
+    _check(prob, 20_000, dev)
+
+
+def test_c3_shape_rings_25_projections(dev):
+    prob = build_problem(ndim=6, num=25, bins=64, xmax=4.0, seed=2, transforms=5, prior_scale=1.0, device=dev,
+                         dist_name="rings", meas_samples=1_000_000, penalty_parameter=500.0)
+    _check(prob, 8_192, dev)
+
+
+def test_c4_shape_gmm_100_projections(dev):
+    prob = build_problem(ndim=6, num=100, bins=64, xmax=3.5, seed=0, transforms=5, prior_scale=3.0, device=dev,
+                         dist_name="gaussian_mixture", meas_samples=1_000_000, penalty_parameter=500.0)
+    _check(prob, 8_192, dev)
+
+
+def test_c5_shape_2d_projections(dev):
+    prob = build_problem(ndim=6, num=12, bins=85, xmax=3.5, seed=0, transforms=5, prior_scale=3.0, device=dev,
+                         dist_name="gaussian_mixture", optics="nd_2d_random", meas_samples=200_000,
+                         penalty_parameter=500.0)
+    _check(prob, 2_048, dev)
