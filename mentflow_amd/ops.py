@@ -42,7 +42,7 @@ class FlowSpec:
         self.image_floats = image_floats
         self.image_index = image_index      # int32 [T * image_floats]  -> flat parameter index or -1
         self.grad_index = grad_index        # int32 [numel]             -> position in the image stack or -1
-        self.bwd_chunk = 1 << 19            # particles per backward chunk (3 KiB of scratch each at d=6)
+        self.bwd_chunk = 1 << 20            # particles per backward chunk (3 KiB of scratch each at d=6)
 
 
 def _layer_fwd(spec: FlowSpec, t: int, image: torch.Tensor, x: torch.Tensor, y: torch.Tensor,

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats and the HBM-traffic PMC passes of the default
+# bench command, written under gpurun_out/profiles_<tag>/ ; tools/summarise_pmc.py turns them into profiles/*.
+# PMC passes are separate runs with --kernel-trace only (never combined with sys/hip traces).
+set -e
+TAG=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG
+mkdir -p $OUT/stats $OUT/fetch $OUT/write $OUT/sq
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats/bench.json 2> $OUT/stats/err.txt
+echo "stats done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > /dev/null 2> $OUT/fetch/err.txt
+echo "fetch done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > /dev/null 2> $OUT/write/err.txt
+echo "write done"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq -- $BENCH > /dev/null 2> $OUT/sq/err.txt
+echo "sq done"
+cd $GRAFT_REPO_ROOT && python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+tail -c 1500 $OUT/bench_default.json

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Turns the rocprofv3 output of tools/collect_profiles.sh (gpurun_out/profiles_<tag>/) into the tracked summaries under
+profiles/: kernel stats, per-kernel HBM traffic per launch (FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md
+§HBM prescribes for wide coalesced reads on gfx950; WRITE_SIZE as reported), SQ utilisation, and traffic.json, which
+bench.py reads to fill roofline.traffic."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"profiles_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+KEY = {"rqs_layer_fwd_kernel": "flow_layer_fwd", "rqs_layer_bwd_kernel": "flow_layer_bwd", "outer_accum_kernel": "outer_accum",
+       "proj_kde1d_fwd_kernel": "kde1d_fwd", "proj_kde1d_bwd_kernel": "kde1d_bwd", "proj_kde2d_fwd_kernel": "kde2d_fwd",
+       "proj_kde2d_bwd_kernel": "kde2d_bwd"}
+
+
+def short(name):
+    for k, v in KEY.items():
+        if k in name:
+            return v
+    return None
+
+
+def one(pattern):
+    files = glob.glob(os.path.join(src, pattern), recursive=True)
+    return files[0] if files else None
+
+
+stats = one("stats/**/*kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+for f in ("stats/bench.json", "bench_default.json"):
+    p = os.path.join(src, f)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_" + f.replace("/", "_")))
+
+
+def per_kernel(csv_path, counter):
+    tot, cnt = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(csv_path)):
+        if r["Counter_Name"] == counter:
+            k = short(r["Kernel_Name"])
+            if k:
+                tot[k] += float(r["Counter_Value"])
+                cnt[k] += 1
+    return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
+
+
+traffic = {}
+fetch, write = one("fetch/**/*counter_collection.csv"), one("write/**/*counter_collection.csv")
+rows = []
+if fetch and write:
+    F, W = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    for k in sorted(set(F) | set(W)):
+        f_kb = F.get(k, (0, 0))[0]
+        w_kb = W.get(k, (0, 0))[0]
+        hbm = (2.0 * f_kb + w_kb) * 1024.0            # FETCH_SIZE counts 64 B per 128-B request on gfx950: doubled
+        traffic[k] = hbm
+        rows.append((k, F.get(k, (0, 0))[1], f_kb, w_kb, hbm))
+    with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w") as fh:
+        fh.write("kernel,launches,FETCH_SIZE_KB_per_launch(raw),WRITE_SIZE_KB_per_launch,HBM_bytes_per_launch(2*fetch+write)\n")
+        for r in rows:
+            fh.write("%s,%d,%.1f,%.1f,%.0f\n" % r)
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+
+sq = one("sq/**/*counter_collection.csv")
+if sq:
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(sq)):
+        k = short(r["Kernel_Name"])
+        if k:
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    names = sorted({n for v in agg.values() for n in v})
+    with open(os.path.join(dst, f"{tag}_sq_counters.csv"), "w") as fh:
+        fh.write("kernel," + ",".join(names) + "\n")
+        for k, v in agg.items():
+            fh.write(k + "," + ",".join("%.4g" % v[n] for n in names) + "\n")
+print("wrote", sorted(os.listdir(dst)))
