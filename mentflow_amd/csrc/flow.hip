@@ -99,9 +99,20 @@ static Sparsity make_sparsity(int d, const int32_t* order, int nblk) {
 // weight-fragment loads of every layer out of the particle-tile loop and then spills them (104 VGPRs spilled in the
 // forward kernel).  A compiler-only memory barrier at the top of each tile keeps the loads next to their MFMAs.
 #define MF_NO_HOIST() asm volatile("" ::: "memory")
-#ifndef MF_ROTATE_DIMS
-#define MF_ROTATE_DIMS 0      // measured: rotating the feature order per wave does not help (5.3 -> 5.7 ms forward)
+
+// Delay the upper half of a workgroup's waves (the SIMD partners of the lower half) at kernel start so that partners
+// run out of phase (one in its MFMA-heavy block while the other is in the spline's VALU work).  MENTFLOW_STAGGER
+// (runtime knob, in units of 64 * 127 clocks of s_sleep) is read by the host wrapper.
+__device__ __forceinline__ void stagger_waves(int wid, int nwaves, int amount) {
+#ifndef MF_EMU
+    if (wid >= nwaves / 2) {
+        for (int i = 0; i < amount; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#else
+    (void)wid; (void)nwaves; (void)amount;
 #endif
+}
+
 
 __device__ __forceinline__ f32x16_t mfma(float a, float b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -380,11 +391,12 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __res
                                                                    float* __restrict__ y,
                                                                    const float* __restrict__ logp_in,
                                                                    float* __restrict__ logp_out, int init_logp,
-                                                                   Sparsity sp) {
+                                                                   Sparsity sp, int stagger) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
     stage_image<BLOCK>(lds, image, g.total);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+    stagger_waves(wid, BLOCK / 64, stagger);
     const int64_t ntiles = (n + 31) / 32;
     for (int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (BLOCK / 64)) {
         MF_NO_HOIST();
@@ -408,10 +420,8 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __res
         float ladj = 0.0f;
         // waves walk the features in rotated order so that the waves sharing a SIMD are not all in the same
         // (MFMA-heavy or VALU-heavy) phase at the same time
-        const int rot = MF_ROTATE_DIMS ? wid % d : 0;
 #pragma unroll 1
-        for (int ii = 0; ii < d; ++ii) {
-            const int i = (ii + rot >= d) ? ii + rot - d : ii + rot;
+        for (int i = 0; i < d; ++i) {
             float v[32], gdummy[32];
             block_linear(lds + g.offW3 + i * HID * WS, lds + g.offB3 + i * HID, h, v, col, hh, sp.kend3[i]);
             float yi, li, gxd;
@@ -452,11 +462,12 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
                                                                    const float* __restrict__ gy,
                                                                    const float* __restrict__ glogp,
                                                                    float* __restrict__ gx, float* __restrict__ scratch,
-                                                                   Sparsity sp) {
+                                                                   Sparsity sp, int stagger) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
     stage_image(lds, image, g.total);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+    stagger_waves(wid, FLOW_WAVES, stagger);
     const int64_t ntiles = (n + 31) / 32;
     const int64_t npad = ntiles * 32;
     float* ACT = scratch;
@@ -492,10 +503,8 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
             gacc[r] = 0.0f;
         }
         const float gl = valid ? -glogp[pc] : 0.0f;
-        const int rot = MF_ROTATE_DIMS ? wid % d : 0;
 #pragma unroll 1
-        for (int ii = 0; ii < d; ++ii) {
-            const int i = (ii + rot >= d) ? ii + rot - d : ii + rot;
+        for (int i = 0; i < d; ++i) {
             float v[32], gv[32];
             const float* W3 = lds + g.offW3 + i * HID * WS;
             block_linear(W3, lds + g.offB3 + i * HID, h[L - 1], v, col, hh, sp.kend3[i]);
@@ -962,6 +971,11 @@ static int flow_check(int d, int L, int64_t n) {
     return 0;
 }
 
+static int flow_stagger() {
+    static const int v = [] { const char* e = getenv("MENTFLOW_STAGGER"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 static int flow_grid(int64_t n, int waves = FLOW_WAVES) {
     const int64_t ntiles = (n + 31) / 32;
     int64_t g = (ntiles + waves - 1) / waves;
@@ -1001,11 +1015,11 @@ extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layer
         if (fwd_block == 1024) {                                                                                      \
             MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL, 1024>), smem);                                            \
             MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL, 1024>), flow_grid(n, 16), 1024, smem, stream, image, d, x, n, y,   \
-                      logp_in, logp_out, init_logp, sp);                                                              \
+                      logp_in, logp_out, init_logp, sp, flow_stagger());                                              \
         } else {                                                                                                      \
             MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL, 512>), smem);                                             \
             MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL, 512>), flow_grid(n, 8), 512, smem, stream, image, d, x, n, y,      \
-                      logp_in, logp_out, init_logp, sp);                                                              \
+                      logp_in, logp_out, init_logp, sp, flow_stagger());                                              \
         }                                                                                                             \
         return check_launch("mf_flow_rqs_layer_fwd");                                                                 \
     }
@@ -1029,7 +1043,7 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
         ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
         MF_ALLOW_DYN_SMEM((rqs_layer_bwd_kernel<KK, LL>), smem);                                                      \
         MF_LAUNCH((rqs_layer_bwd_kernel<KK, LL>), flow_grid(n), FLOW_BLOCK, smem, stream, image, d, x, n, gy, glogp,   \
-                  gx, scratch, sp);                                                                                   \
+                  gx, scratch, sp, flow_stagger());                                                                                \
         launched = true;                                                                                              \
     }
     MF_RQS_CASES(X)

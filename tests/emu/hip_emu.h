@@ -212,6 +212,7 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
+static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }

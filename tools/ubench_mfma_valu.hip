@@ -19,6 +19,17 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, int mode) {
     const bool do_valu = (mode == 1) || (mode == 2 && (wid & 1)) || mode == 3 || (mode == 5 && (wid & 1));
     const bool do_bf16 = (mode == 4) || (mode == 5 && !(wid & 1));
     for (int it = 0; it < iters; ++it) {
+        if (mode == 6) {      // fine-grained interleave inside every wave: 1 MFMA, 16 FMAs, repeated 4 times
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                v0 = fmaf(v0, a, b); v1 = fmaf(v1, a, b); v2 = fmaf(v2, a, b); v3 = fmaf(v3, a, b);
+                v4 = fmaf(v4, a, b); v5 = fmaf(v5, a, b); v6 = fmaf(v6, a, b); v7 = fmaf(v7, a, b);
+                v0 = fmaf(v0, a, b); v1 = fmaf(v1, a, b); v2 = fmaf(v2, a, b); v3 = fmaf(v3, a, b);
+                v4 = fmaf(v4, a, b); v5 = fmaf(v5, a, b); v6 = fmaf(v6, a, b); v7 = fmaf(v7, a, b);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         if (do_mfma) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -45,8 +56,9 @@ int main() {
     hipMalloc(&out, 256 * 512 * 4);
     const int iters = 20000;
     const char* names[] = {"all waves f32 MFMA (4/iter)", "all waves VALU (64 fma/iter)", "even MFMA f32 / odd VALU",
-                           "every wave both", "all waves bf16 MFMA (8/iter)", "even bf16 MFMA / odd VALU"};
-    for (int mode = 0; mode < 6; ++mode) {
+                           "every wave both", "all waves bf16 MFMA (8/iter)", "even bf16 MFMA / odd VALU",
+                           "every wave interleaved 1:16"};
+    for (int mode = 0; mode < 7; ++mode) {
         hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);
         k<<<256, 512>>>(out, 100, mode);
