@@ -9,6 +9,7 @@ from . import diagnostics
 from . import dist
 from . import entropy
 from . import generate
+from . import graph
 from . import loss
 from . import ops
 from . import prior

@@ -119,11 +119,11 @@ class MENTFlow(nn.Module):
         pieces = []
         for diagnostic, rows, meas, _ in groups:
             if isinstance(diagnostic, Histogram1D):
-                S = ops.ProjKde1dFn.apply(x, rows[0], diagnostic.coords, float(diagnostic.bandwidth),
+                S = ops.ProjKde1dFn.apply(x, rows[0], diagnostic.coords, diagnostic.bandwidth_value,
                                           ops.kde_radius(diagnostic.bandwidth_bins))
             else:
                 S = ops.ProjKde2dFn.apply(x, rows[0], rows[1], diagnostic.coords_x, diagnostic.coords_y,
-                                          float(diagnostic.bandwidth_x), float(diagnostic.bandwidth_y),
+                                          diagnostic.bandwidth_values[0], diagnostic.bandwidth_values[1],
                                           ops.kde_radius(diagnostic.bandwidth_bins[0]),
                                           ops.kde_radius(diagnostic.bandwidth_bins[1]))
             pieces.append(S.reshape(-1))
@@ -139,9 +139,9 @@ class MENTFlow(nn.Module):
         for (diagnostic, rows, meas, positions), S in zip(groups, pieces):
             P = meas.shape[0]
             if isinstance(diagnostic, Histogram1D):
-                pre_scale, cell, div = 1.0 / n_total, float(diagnostic.resolution), float(meas.shape[1])
+                pre_scale, cell, div = 1.0 / n_total, diagnostic.resolution_value, float(meas.shape[1])
             else:
-                pre_scale, cell = 1.0, float(diagnostic.resolution_x * diagnostic.resolution_y)
+                pre_scale, cell = 1.0, diagnostic.resolution_values[0] * diagnostic.resolution_values[1]
                 div = float(diagnostic.coords_x.numel())
             if kind != "kld":
                 div = float(meas.shape[1])

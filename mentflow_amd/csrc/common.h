@@ -30,8 +30,15 @@ constexpr int NUM_CU = 256;   // MI355X: 8 XCDs x 32 CUs
 #define MF_DYN_SMEM(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_[]; \
     type* name = reinterpret_cast<type*>(name##_raw_)
 // LDS beyond 64 KiB per workgroup has to be requested explicitly (gfx950 allows 160 KiB)
-#define MF_ALLOW_DYN_SMEM(kernel, bytes) \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+#define MF_ALLOW_DYN_SMEM(kernel, bytes)                                                                              \
+    do {                                                                                                              \
+        static size_t allowed_ = 0;        /* raised once per kernel (and again only if a larger size is needed) */    \
+        if ((size_t)(bytes) > allowed_) {                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)(bytes));                                                                  \
+            allowed_ = (size_t)(bytes);                                                                               \
+        }                                                                                                             \
+    } while (0)
 #endif
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -489,8 +489,8 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, int64_t tile
 
 // =========================================================================================== backward, RQS
 // scratch: ACT[L][npad][64] | GPRE[L][npad][64] | GPHI[d][npad][64],  npad = ntiles*32
-template <int K, int L>
-__global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* __restrict__ image, int d,
+template <int K, int L, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void rqs_layer_bwd_kernel(const float* __restrict__ image, int d,
                                                                    const float* __restrict__ x, int64_t n,
                                                                    const float* __restrict__ gy,
                                                                    const float* __restrict__ glogp,
@@ -498,15 +498,15 @@ __global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_kernel(const float* 
                                                                    Sparsity sp, int stagger) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
-    stage_image(lds, image, g.total);
+    stage_image<BLOCK>(lds, image, g.total);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
-    stagger_waves(wid, FLOW_WAVES, stagger);
+    stagger_waves(wid, BLOCK / 64, stagger);
     const int64_t ntiles = (n + 31) / 32;
     const int64_t npad = ntiles * 32;
     float* ACT = scratch;
     float* GPRE = ACT + (int64_t)L * npad * 64;
     float* GPHI = GPRE + (int64_t)L * npad * 64;
-    for (int64_t tile = (int64_t)blockIdx.x * FLOW_WAVES + wid; tile < ntiles; tile += (int64_t)gridDim.x * FLOW_WAVES) {
+    for (int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (BLOCK / 64)) {
         MF_NO_HOIST();
         const int64_t p = tile * 32 + col;
         const bool valid = p < n;
@@ -1329,24 +1329,23 @@ extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layer
     if (n == 0) return 0;
     const Sparsity sp = make_sparsity(d, order, d);
     const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, d).total;
-    // 1024-thread workgroups (4 waves per SIMD at <= 128 VGPRs) hide LDS and spline latency better than 512
-    static const int fwd_block = [] {
-        const char* e = getenv("MENTFLOW_FWD_BLOCK");
-        return (e && atoi(e) == 512) ? 512 : 1024;
-    }();
+    // Workgroup size: 1024 threads (4 waves per SIMD at <= 128 VGPRs) for big batches; small batches (the reference's
+    // 25 000 particles = 782 tiles) use fewer waves per workgroup so that the tiles spread over all 256 CUs.
+    const int64_t nt = (n + 31) / 32;
+    static const int fwd_block_env = [] { const char* e = getenv("MENTFLOW_FWD_BLOCK"); return e ? atoi(e) : 0; }();
+    const int fwd_block = fwd_block_env ? fwd_block_env : (nt <= 4 * NUM_CU ? 256 : (nt <= 8 * NUM_CU ? 512 : 1024));
+#define XB(KK, LL, BB)                                                                                                \
+    if (fwd_block == BB) {                                                                                            \
+        MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL, BB>), smem);                                                  \
+        MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL, BB>), flow_grid(n, BB / 64), BB, smem, stream, image, d, x, n, y,      \
+                  logp_in, logp_out, init_logp, sp, flow_stagger());                                                  \
+        return check_launch("mf_flow_rqs_layer_fwd");                                                                 \
+    }
 #define X(KK, LL)                                                                                                     \
     if (bins == KK && hidden_layers == LL) {                                                                          \
         ProfScope prof(PK_FLOW_FWD, stream);                                                                          \
-        if (fwd_block == 1024) {                                                                                      \
-            MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL, 1024>), smem);                                            \
-            MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL, 1024>), flow_grid(n, 16), 1024, smem, stream, image, d, x, n, y,   \
-                      logp_in, logp_out, init_logp, sp, flow_stagger());                                              \
-        } else {                                                                                                      \
-            MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL, 512>), smem);                                             \
-            MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL, 512>), flow_grid(n, 8), 512, smem, stream, image, d, x, n, y,      \
-                      logp_in, logp_out, init_logp, sp, flow_stagger());                                              \
-        }                                                                                                             \
-        return check_launch("mf_flow_rqs_layer_fwd");                                                                 \
+        XB(KK, LL, 256) XB(KK, LL, 512) XB(KK, LL, 1024)                                                              \
+        return fail("MENTFLOW_FWD_BLOCK must be 256, 512 or 1024");                                                   \
     }
     MF_RQS_CASES(X)
 #undef X
@@ -1389,12 +1388,20 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
 #undef XW
         }
     }
+    const int64_t ntb = (n + 31) / 32;
+    const int bwd_block = ntb <= 4 * NUM_CU ? 256 : 512;      // small batches: one tile per SIMD on as many CUs as possible
 #define X(KK, LL)                                                                                                     \
     if (!launched && bins == KK && hidden_layers == LL) {                                                             \
         ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
-        MF_ALLOW_DYN_SMEM((rqs_layer_bwd_kernel<KK, LL>), smem);                                                      \
-        MF_LAUNCH((rqs_layer_bwd_kernel<KK, LL>), flow_grid(n), FLOW_BLOCK, smem, stream, image, d, x, n, gy, glogp,   \
-                  gx, scratch, sp, flow_stagger());                                                                                \
+        if (bwd_block == 256) {                                                                                       \
+            MF_ALLOW_DYN_SMEM((rqs_layer_bwd_kernel<KK, LL, 256>), smem);                                             \
+            MF_LAUNCH((rqs_layer_bwd_kernel<KK, LL, 256>), flow_grid(n, 4), 256, smem, stream, image, d, x, n, gy,     \
+                      glogp, gx, scratch, sp, flow_stagger());                                                        \
+        } else {                                                                                                      \
+            MF_ALLOW_DYN_SMEM((rqs_layer_bwd_kernel<KK, LL, 512>), smem);                                             \
+            MF_LAUNCH((rqs_layer_bwd_kernel<KK, LL, 512>), flow_grid(n, 8), 512, smem, stream, image, d, x, n, gy,     \
+                      glogp, gx, scratch, sp, flow_stagger());                                                        \
+        }                                                                                                             \
         launched = true;                                                                                              \
     }
     MF_RQS_CASES(X)
@@ -1405,7 +1412,10 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
     if (check_launch("mf_flow_rqs_layer_bwd")) return 1;
     const int64_t ntiles = (n + 31) / 32;
     static const int oa_mult = [] { const char* e = getenv("MENTFLOW_OA_MULT"); return e ? atoi(e) : 2; }();
-    int64_t G = ntiles < oa_mult * NUM_CU ? ntiles : oa_mult * NUM_CU;
+    // every workgroup ends with a 4096-atomics-per-wave flush of its accumulators: give it at least 8 tiles of work
+    int64_t G = (ntiles + 7) / 8;
+    if (G > oa_mult * NUM_CU) G = oa_mult * NUM_CU;
+    if (G < 1) G = 1;
     const int nwaves = d > hidden_layers ? d : hidden_layers;
     if (nwaves > OA_MAX_WAVES) return fail("too many linear blocks for the gradient kernel");
     ProfScope prof(PK_OUTER_ACCUM, stream);
@@ -1466,7 +1476,9 @@ extern "C" int mf_flow_affine_layer_bwd(const float* image, int d, int hidden_la
     if (!launched) return fail("no affine kernel instance for hidden_layers=%d (built: 2, 3)", hidden_layers);
     if (check_launch("mf_flow_affine_layer_bwd")) return 1;
     const int64_t ntiles = (n + 31) / 32;
-    int64_t G = ntiles < 4 * NUM_CU ? ntiles : 4 * NUM_CU;
+    int64_t G = (ntiles + 7) / 8;
+    if (G > 2 * NUM_CU) G = 2 * NUM_CU;
+    if (G < 1) G = 1;
     ProfScope prof(PK_OUTER_ACCUM, stream);
     MF_LAUNCH(outer_accum_kernel, dim3((unsigned)G, 2), 64 * hidden_layers, 0, stream, (const float*)scratch, x, n, d,
               hidden_layers, 1, gimage, sp);

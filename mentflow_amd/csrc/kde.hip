@@ -578,7 +578,7 @@ extern "C" int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* 
         const int ngroups = (P + Pg - 1) / Pg;
         const int ds = d | 1;
         const size_t smem = sizeof(u64) * (size_t)Pg * B + sizeof(float) * ((size_t)Pg * ds + B);
-        int G = grid_for(n, KDE_BLOCK * 4, (NUM_CU * 8 + ngroups - 1) / ngroups);
+        int G = grid_for(n, KDE_BLOCK, (NUM_CU * 8 + ngroups - 1) / ngroups);   // >= 256 particles per workgroup
         if ((n + G - 1) / G > KDE_MAX_PER_WG) G = (int)((n + KDE_MAX_PER_WG - 1) / KDE_MAX_PER_WG);
         ProfScope prof(PK_KDE1D_FWD, stream);
         if (R == 4) {
@@ -640,7 +640,7 @@ extern "C" int mf_proj_kde2d_fwd(const float* x, int64_t n, int d, const float* 
         const int ds = d | 1;
         const size_t smem = sizeof(u64) * (size_t)Pg * BB + sizeof(float) * (2 * (size_t)Pg * ds + Bx + By);
         const int ngroups = (P + Pg - 1) / Pg;
-        int G = grid_for(n, KDE_BLOCK * 4, (NUM_CU * 8 + ngroups - 1) / ngroups);
+        int G = grid_for(n, KDE_BLOCK, (NUM_CU * 8 + ngroups - 1) / ngroups);   // >= 256 particles per workgroup
         if ((n + G - 1) / G > KDE_MAX_PER_WG) G = (int)((n + KDE_MAX_PER_WG - 1) / KDE_MAX_PER_WG);
         ProfScope prof(PK_KDE2D_FWD, stream);
         MF_ALLOW_DYN_SMEM(proj_kde2d_fwd_kernel, smem);
@@ -678,7 +678,7 @@ extern "C" int mf_proj_hist1d_counts(const float* x, int64_t n, int d, const flo
     const int Pg = (KDE_LDS_FLOATS / B) < P ? (KDE_LDS_FLOATS / B) : P;
     const int ngroups = (P + Pg - 1) / Pg;
     const size_t smem = sizeof(float) * ((size_t)Pg * B + (size_t)Pg * d + B + 1);
-    const int G = grid_for(n, KDE_BLOCK * 4, (NUM_CU * 8 + ngroups - 1) / ngroups);
+    const int G = grid_for(n, KDE_BLOCK, (NUM_CU * 8 + ngroups - 1) / ngroups);   // >= 256 particles per workgroup
     MF_ALLOW_DYN_SMEM(proj_hist1d_kernel, smem);
     MF_LAUNCH(proj_hist1d_kernel, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, edges, B, counts);
     return check_launch("mf_proj_hist1d_counts");
@@ -694,7 +694,7 @@ extern "C" int mf_proj_hist2d_counts(const float* x, int64_t n, int d, const flo
     if (hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)P * Bx * By, (hipStream_t)stream) != hipSuccess) return fail("memset");
     if (n == 0) return 0;
     const int ngroups = (P + Pg - 1) / Pg;
-    const int G = grid_for(n, KDE_BLOCK * 4, (NUM_CU * 8 + ngroups - 1) / ngroups);
+    const int G = grid_for(n, KDE_BLOCK, (NUM_CU * 8 + ngroups - 1) / ngroups);   // >= 256 particles per workgroup
     MF_ALLOW_DYN_SMEM(proj_hist2d_kernel, smem);
     MF_LAUNCH(proj_hist2d_kernel, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V0, V1, P, Pg, edges_x, Bx, edges_y,
               By, counts);

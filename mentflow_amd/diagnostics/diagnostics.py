@@ -83,6 +83,10 @@ class Histogram1D(Histogram):
         self.register_buffer("coords", coords_from_edges(self.edges))
         self.register_buffer("resolution", edges[1] - edges[0])
         self.register_buffer("bandwidth", bandwidth * self.resolution)
+        # host copies of the two scalars every launch needs (read once here: no device->host sync per call, and the
+        # step stays capturable into a hipGraph)
+        self.resolution_value = float(self.resolution)
+        self.bandwidth_value = float(self.bandwidth)
 
     def projection_rows(self, matrix: torch.Tensor) -> List[torch.Tensor]:
         """u[:, axis] = x . matrix[axis]  (or  (x @ M.T) . direction = x . (direction @ M))."""
@@ -94,8 +98,8 @@ class Histogram1D(Histogram):
         """All P projections in one launch: [P, B] normalised histograms (kde) or densities (hard bins)."""
         V = rows[0].to(torch.float32).contiguous()
         if self.kde:
-            S = ops.ProjKde1dFn.apply(x, V, self.coords, float(self.bandwidth), ops.kde_radius(self.bandwidth_bins))
-            ghat, _ = ops.HistNormDiscFn.apply(S, None, True, 1.0 / x.shape[0], float(self.resolution), 1.0e-10, 0, 0.0, 1.0)
+            S = ops.ProjKde1dFn.apply(x, V, self.coords, self.bandwidth_value, ops.kde_radius(self.bandwidth_bins))
+            ghat, _ = ops.HistNormDiscFn.apply(S, None, True, 1.0 / x.shape[0], self.resolution_value, 1.0e-10, 0, 0.0, 1.0)
             return ghat
         counts = ops.proj_hist_counts_1d(x.detach(), V, self.edges).to(torch.float32)
         widths = (self.edges[1:] - self.edges[:-1])[None, :]
@@ -123,6 +127,8 @@ class Histogram2D(Histogram):
         self.register_buffer("resolution_y", self.edges_y[1] - self.edges_y[0])
         self.register_buffer("bandwidth_x", bx * self.resolution_x)
         self.register_buffer("bandwidth_y", by * self.resolution_y)
+        self.resolution_values = (float(self.resolution_x), float(self.resolution_y))
+        self.bandwidth_values = (float(self.bandwidth_x), float(self.bandwidth_y))
 
     @property
     def edges(self) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -135,12 +141,12 @@ class Histogram2D(Histogram):
         V0 = rows[0].to(torch.float32).contiguous()
         V1 = rows[1].to(torch.float32).contiguous()
         if self.kde:
-            S = ops.ProjKde2dFn.apply(x, V0, V1, self.coords_x, self.coords_y, float(self.bandwidth_x),
-                                      float(self.bandwidth_y), ops.kde_radius(self.bandwidth_bins[0]),
+            S = ops.ProjKde2dFn.apply(x, V0, V1, self.coords_x, self.coords_y, self.bandwidth_values[0],
+                                      self.bandwidth_values[1], ops.kde_radius(self.bandwidth_bins[0]),
                                       ops.kde_radius(self.bandwidth_bins[1]))
             P, Bx, By = S.shape
             ghat, _ = ops.HistNormDiscFn.apply(S.view(P, Bx * By), None, True, 1.0,
-                                               float(self.resolution_x * self.resolution_y), 1.0e-10, 0, 0.0, 1.0)
+                                               self.resolution_values[0] * self.resolution_values[1], 1.0e-10, 0, 0.0, 1.0)
             return ghat.view(P, Bx, By)
         counts = ops.proj_hist_counts_2d(x.detach(), V0, V1, self.edges_x, self.edges_y).to(torch.float32)
         area = (self.edges_x[1:] - self.edges_x[:-1])[:, None] * (self.edges_y[1:] - self.edges_y[:-1])[None, :]
