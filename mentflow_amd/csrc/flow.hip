@@ -138,7 +138,7 @@ __device__ __forceinline__ f32x16_t bias_tile(const float* b, int rt, int hh) {
 // Steps are issued in groups of four under ONE branch, so that the four weight-fragment ds_reads are in flight together
 // instead of one exposed LDS round trip per MFMA (bounds are rounded to the group: the extra steps multiply zeros).
 // (Measured alternatives: one branch per step 8 % slower; a two-deep software-pipelined chain with per-step bounds
-// 14 % slower — too many tiny basic blocks.)
+// 14 % slower — too many tiny basic blocks; requesting group g + 1 before the MFMAs of group g 4 % slower.)
 __device__ __forceinline__ constexpr int kcol(int s) { return 32 * (s >> 4) + rowmap(s & 15, 0); }
 
 __device__ __forceinline__ void linear64s(const float* W, int stride, const float* b, const f32x16_t (&in)[2],
@@ -236,14 +236,10 @@ __device__ __forceinline__ void input_layer(const float* W0, const float* b0, in
     relu2(h);
 }
 
-// exp(x) for |x| < ~80 as one v_exp_f32 with a compensated argument (x*log2(e) split into hi + lo so that the result
-// is good to ~1 ulp instead of |x| ulp); the library expf costs about three times as many VALU slots.
-__device__ __forceinline__ float fast_exp(float x) {
-    const float L2E = 1.4426950408889634f;
-    const float hi = x * L2E;
-    const float lo = fmaf(x, L2E, -hi) + x * 1.925963033500810e-8f;     // rounding error of hi + low bits of log2(e)
-    return __builtin_amdgcn_exp2f(hi) * fmaf(lo, 0.6931471805599453f, 1.0f);
-}
+// exp(x) as one v_exp_f32: exp2(x * log2(e)).  Only used on soft-clipped arguments (|x| < 6.91), where the rounding of
+// the product costs at most |x| * 1.44 * 2^-24 < 6e-7 relative — the same order as the fp32 rounding of everything
+// downstream; a compensated argument (hi + lo split) was measured to cost ~5 % of the forward kernel.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 __device__ __forceinline__ float soft_clip(float v, float a) { return v * fast_rcp(fmaf(fabsf(v), a, 1.0f)); }
 __device__ __forceinline__ float soft_clip_grad(float v, float a) {
