@@ -115,6 +115,12 @@ int mf_proj_kde2d_bwd(const float* x, int64_t n, int d, const float* V0, const f
                       const float* coords_x, int Bx, float sigma_x, int radius_x, const float* coords_y, int By,
                       float sigma_y, int radius_y, const float* gS, float* gx, int accumulate, void* stream);
 
+/* Thin multipole kick ahead of a linear map (the non-linear transport of experiments/rec_2d/nonlinear:
+ * mentflow/simulate/transform.py:78-146, orders 3..5, k = strength / (order-1)!): u = kick(x), and its adjoint.   */
+int mf_multipole_kick_fwd(const float* x, int64_t n, int d, int order, float k, int skew, float* u, void* stream);
+int mf_multipole_kick_bwd(const float* x, int64_t n, int d, int order, float k, int skew, const float* gu, float* gx,
+                          void* stream);
+
 /* Hard-binned projection histograms (measurement generation / eval): counts[p,k] of u = x.V_p in uniform bins
  * [lo, lo + B*delta], out-of-range ignored, last bin right-inclusive: torch.histogram semantics
  * (mentflow/diagnostics/diagnostics.py:128-131); density/renormalisation is done by the caller.                */

@@ -46,6 +46,8 @@ PROTOTYPES = {
                                  _ptr, _ptr, _ptr]),
     "mf_proj_kde2d_bwd": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i32, _ptr, _i32, _f32, _i32, _ptr, _i32, _f32, _i32,
                                  _ptr, _ptr, _i32, _ptr]),
+    "mf_multipole_kick_fwd": (_i32, [_ptr, _i64, _i32, _i32, _f32, _i32, _ptr, _ptr]),
+    "mf_multipole_kick_bwd": (_i32, [_ptr, _i64, _i32, _i32, _f32, _i32, _ptr, _ptr, _ptr]),
     "mf_proj_hist1d_counts": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _i32, _ptr, _ptr]),
     "mf_proj_hist2d_counts": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i32, _ptr, _i32, _ptr, _i32, _ptr, _ptr]),
     "mf_hist_norm_discrepancy_fwd": (_i32, [_ptr, _i32, _i32, _i32, _f32, _f32, _f32, _ptr, _i32, _f32, _f32, _ptr, _ptr,

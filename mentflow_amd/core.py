@@ -13,6 +13,7 @@ from .entropy import EmptyEntropyEstimator, MonteCarloEntropyEstimator
 from .generate import GenerativeModel
 from .loss import kl_divergence
 from .simulate import forward, group_measurements
+from .simulate.simulate import apply_pre
 from .utils import unravel
 
 
@@ -84,13 +85,13 @@ class MENTFlow(nn.Module):
                 order[(i, j)] = pos
                 pos += 1
         plan = []
-        for diagnostic, slots, rows in groups.values():
+        for diagnostic, pre, slots, rows in groups.values():
             if not diagnostic.kde or (diagnostic.noise and diagnostic.noise_scale > 0.0):
                 return None
             stacked = [torch.stack([r[k] for r in rows]).to(torch.float32).contiguous() for k in range(len(rows[0]))]
             meas = torch.stack([self.measurements[i][j] for (i, j) in slots]).to(torch.float32)
             meas = meas.reshape(len(slots), -1).contiguous()
-            plan.append((diagnostic, stacked, meas, [order[s] for s in slots]))
+            plan.append((diagnostic, stacked, meas, [order[s] for s in slots], pre))
         self._plan, self._plan_key = (plan, pos, kind), key
         return self._plan
 
@@ -116,13 +117,18 @@ class MENTFlow(nn.Module):
         x, log_prob = self.generator.sample_and_log_prob(n_local)
 
         use_entropy = isinstance(self.entropy_estimator, MonteCarloEntropyEstimator)
+        if use_entropy and log_prob is None:
+            raise ValueError("the Monte-Carlo entropy estimator needs a generator with a density (log_prob is None)")
+        if mfdist.is_active() and not hasattr(self.generator, "grad_reduce"):
+            raise NotImplementedError("data-parallel training is wired for the flow generators only")
         pieces = []
-        for diagnostic, rows, meas, _ in groups:
+        for diagnostic, rows, meas, _, pre in groups:
+            xt = apply_pre(x, pre)
             if isinstance(diagnostic, Histogram1D):
-                S = ops.ProjKde1dFn.apply(x, rows[0], diagnostic.coords, diagnostic.bandwidth_value,
+                S = ops.ProjKde1dFn.apply(xt, rows[0], diagnostic.coords, diagnostic.bandwidth_value,
                                           ops.kde_radius(diagnostic.bandwidth_bins))
             else:
-                S = ops.ProjKde2dFn.apply(x, rows[0], rows[1], diagnostic.coords_x, diagnostic.coords_y,
+                S = ops.ProjKde2dFn.apply(xt, rows[0], rows[1], diagnostic.coords_x, diagnostic.coords_y,
                                           diagnostic.bandwidth_values[0], diagnostic.bandwidth_values[1],
                                           ops.kde_radius(diagnostic.bandwidth_bins[0]),
                                           ops.kde_radius(diagnostic.bandwidth_bins[1]))
@@ -136,7 +142,7 @@ class MENTFlow(nn.Module):
 
         D_slots: List[Optional[torch.Tensor]] = [None] * n_meas
         D_sum = None
-        for (diagnostic, rows, meas, positions), S in zip(groups, pieces):
+        for (diagnostic, rows, meas, positions, _pre), S in zip(groups, pieces):
             P = meas.shape[0]
             if isinstance(diagnostic, Histogram1D):
                 pre_scale, cell, div = 1.0 / n_total, diagnostic.resolution_value, float(meas.shape[1])

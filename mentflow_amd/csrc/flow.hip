@@ -100,20 +100,6 @@ static Sparsity make_sparsity(int d, const int32_t* order, int nblk) {
 // forward kernel).  A compiler-only memory barrier at the top of each tile keeps the loads next to their MFMAs.
 #define MF_NO_HOIST() asm volatile("" ::: "memory")
 
-// Delay the upper half of a workgroup's waves (the SIMD partners of the lower half) at kernel start so that partners
-// run out of phase (one in its MFMA-heavy block while the other is in the spline's VALU work).  MENTFLOW_STAGGER
-// (runtime knob, in units of 64 * 127 clocks of s_sleep) is read by the host wrapper.
-__device__ __forceinline__ void stagger_waves(int wid, int nwaves, int amount) {
-#ifndef MF_EMU
-    if (wid >= nwaves / 2) {
-        for (int i = 0; i < amount; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#else
-    (void)wid; (void)nwaves; (void)amount;
-#endif
-}
-
-
 __device__ __forceinline__ f32x16_t mfma(float a, float b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -420,12 +406,11 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __res
                                                                    float* __restrict__ y,
                                                                    const float* __restrict__ logp_in,
                                                                    float* __restrict__ logp_out, int init_logp,
-                                                                   Sparsity sp, int stagger) {
+                                                                   Sparsity sp) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
     stage_image<BLOCK>(lds, image, g.total);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
-    stagger_waves(wid, BLOCK / 64, stagger);
     const int64_t ntiles = (n + 31) / 32;
     for (int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (BLOCK / 64)) {
         MF_NO_HOIST();
@@ -491,12 +476,11 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_bwd_kernel(const float* __res
                                                                    const float* __restrict__ gy,
                                                                    const float* __restrict__ glogp,
                                                                    float* __restrict__ gx, float* __restrict__ scratch,
-                                                                   Sparsity sp, int stagger) {
+                                                                   Sparsity sp) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
     stage_image<BLOCK>(lds, image, g.total);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
-    stagger_waves(wid, BLOCK / 64, stagger);
     const int64_t ntiles = (n + 31) / 32;
     const int64_t npad = ntiles * 32;
     float* ACT = scratch;
@@ -1292,11 +1276,6 @@ static int flow_check(int d, int L, int64_t n) {
     return 0;
 }
 
-static int flow_stagger() {
-    static const int v = [] { const char* e = getenv("MENTFLOW_STAGGER"); return e ? atoi(e) : 0; }();
-    return v;
-}
-
 static int flow_grid(int64_t n, int waves = FLOW_WAVES) {
     const int64_t ntiles = (n + 31) / 32;
     int64_t g = (ntiles + waves - 1) / waves;
@@ -1334,7 +1313,7 @@ extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layer
     if (fwd_block == BB) {                                                                                            \
         MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL, BB>), smem);                                                  \
         MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL, BB>), flow_grid(n, BB / 64), BB, smem, stream, image, d, x, n, y,      \
-                  logp_in, logp_out, init_logp, sp, flow_stagger());                                                  \
+                  logp_in, logp_out, init_logp, sp);                                                  \
         return check_launch("mf_flow_rqs_layer_fwd");                                                                 \
     }
 #define X(KK, LL)                                                                                                     \
@@ -1392,11 +1371,11 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
         if (bwd_block == 256) {                                                                                       \
             MF_ALLOW_DYN_SMEM((rqs_layer_bwd_kernel<KK, LL, 256>), smem);                                             \
             MF_LAUNCH((rqs_layer_bwd_kernel<KK, LL, 256>), flow_grid(n, 4), 256, smem, stream, image, d, x, n, gy,     \
-                      glogp, gx, scratch, sp, flow_stagger());                                                        \
+                      glogp, gx, scratch, sp);                                                        \
         } else {                                                                                                      \
             MF_ALLOW_DYN_SMEM((rqs_layer_bwd_kernel<KK, LL, 512>), smem);                                             \
             MF_LAUNCH((rqs_layer_bwd_kernel<KK, LL, 512>), flow_grid(n, 8), 512, smem, stream, image, d, x, n, gy,     \
-                      glogp, gx, scratch, sp, flow_stagger());                                                        \
+                      glogp, gx, scratch, sp);                                                        \
         }                                                                                                             \
         launched = true;                                                                                              \
     }

@@ -534,6 +534,67 @@ __global__ __launch_bounds__(KDE_BLOCK) void gather_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------ multipole kick
+// mentflow/simulate/transform.py:78-146 (MultipoleTransform.forward): z = x + i y (x = X[:,0], y = X[:,2] or 0),
+// zn = z^(order-1);  non-skew: U[:,1] = X[:,1] - k Re(zn), U[:,3] = X[:,1] + k Im(zn)  (sic: the reference writes
+// X[:,1], not X[:,3]);  skew: U[:,1] = X[:,1] + k Im(zn), U[:,3] = X[:,3] + k Re(zn);  k = strength / (order-1)!.
+__device__ __forceinline__ void cpow(float x, float y, int m, float& re, float& im) {
+    re = 1.0f;
+    im = 0.0f;
+    for (int i = 0; i < m; ++i) {
+        const float t = re * x - im * y;
+        im = re * y + im * x;
+        re = t;
+    }
+}
+
+__global__ __launch_bounds__(KDE_BLOCK) void multipole_fwd_kernel(const float* __restrict__ X, int64_t n, int d, int m,
+                                                                   float k, int skew, float* __restrict__ U) {
+    for (int64_t p = (int64_t)blockIdx.x * KDE_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * KDE_BLOCK) {
+        const float* xr = X + p * d;
+        float* ur = U + p * d;
+        const float x = xr[0], y = d > 2 ? xr[2] : 0.0f;
+        float re, im;
+        cpow(x, y, m, re, im);
+        for (int j = 0; j < d; ++j) ur[j] = xr[j];
+        if (skew) {
+            ur[1] = xr[1] + k * im;
+            if (d > 2) ur[3] = xr[3] + k * re;
+        } else {
+            ur[1] = xr[1] - k * re;
+            if (d > 2) ur[3] = xr[1] + k * im;
+        }
+    }
+}
+
+// gX = J^T gU with d Re(zn)/dx = m Re(z^(m-1)), d Re/dy = -m Im(z^(m-1)), d Im/dx = m Im(z^(m-1)), d Im/dy = m Re(z^(m-1))
+__global__ __launch_bounds__(KDE_BLOCK) void multipole_bwd_kernel(const float* __restrict__ X, int64_t n, int d, int m,
+                                                                   float k, int skew, const float* __restrict__ gU,
+                                                                   float* __restrict__ gX) {
+    for (int64_t p = (int64_t)blockIdx.x * KDE_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * KDE_BLOCK) {
+        const float* xr = X + p * d;
+        const float* gu = gU + p * d;
+        float* gx = gX + p * d;
+        const float x = xr[0], y = d > 2 ? xr[2] : 0.0f;
+        float re1, im1;
+        cpow(x, y, m - 1, re1, im1);
+        const float dre_dx = m * re1, dre_dy = -(float)m * im1, dim_dx = m * im1, dim_dy = m * re1;
+        for (int j = 0; j < d; ++j) gx[j] = gu[j];
+        const float g1 = gu[1], g3 = d > 2 ? gu[3] : 0.0f;
+        if (skew) {
+            gx[0] += k * (g1 * dim_dx + g3 * dre_dx);
+            if (d > 2) gx[2] += k * (g1 * dim_dy + g3 * dre_dy);
+        } else {
+            gx[0] += k * (-g1 * dre_dx + g3 * dim_dx);
+            if (d > 2) {
+                gx[2] += k * (-g1 * dre_dy + g3 * dim_dy);
+                gx[1] += g3;          // U[:,3] reads X[:,1] in the reference
+                gx[3] -= g3;          // ... and not X[:,3]
+            }
+        }
+    }
+}
+
 static int grid_for(int64_t n, int per_block, int cap) {
     int64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -739,4 +800,21 @@ extern "C" int mf_scale_rows(const float* x, int64_t n, int d, const float* coef
     MF_LAUNCH(scale_rows_kernel, grid_for(total, KDE_BLOCK * 4, 4096), KDE_BLOCK, 0, stream, x, total, coef, cscale, gx,
               accumulate);
     return check_launch("mf_scale_rows");
+}
+
+extern "C" int mf_multipole_kick_fwd(const float* x, int64_t n, int d, int order, float k, int skew, float* u, void* stream) {
+    if (order < 3 || order > 5) return fail("MultipoleTransform requires 3 <= order <= 5 (reference: transform.py:116-132)");
+    if (d < 2 || (d > 2 && d < 4)) return fail("multipole kick needs d = 2 or d >= 4");
+    if (n <= 0) return 0;
+    MF_LAUNCH(multipole_fwd_kernel, grid_for(n, KDE_BLOCK, 4096), KDE_BLOCK, 0, stream, x, n, d, order - 1, k, skew, u);
+    return check_launch("mf_multipole_kick_fwd");
+}
+
+extern "C" int mf_multipole_kick_bwd(const float* x, int64_t n, int d, int order, float k, int skew, const float* gu, float* gx,
+                                      void* stream) {
+    if (order < 3 || order > 5) return fail("MultipoleTransform requires 3 <= order <= 5");
+    if (d < 2 || (d > 2 && d < 4)) return fail("multipole kick needs d = 2 or d >= 4");
+    if (n <= 0) return 0;
+    MF_LAUNCH(multipole_bwd_kernel, grid_for(n, KDE_BLOCK, 4096), KDE_BLOCK, 0, stream, x, n, d, order - 1, k, skew, gu, gx);
+    return check_launch("mf_multipole_kick_bwd");
 }

@@ -3,3 +3,4 @@ from .base import GenerativeModel
 from .flows import AutoregressiveFlow
 from .build import build_generator
 from .build import build_flow
+from .nn import NNGenerator, NNTransform

@@ -5,6 +5,7 @@ import torch
 
 from .base import GenerativeModel
 from .flows import AutoregressiveFlow
+from .nn import NNGenerator, NNTransform
 
 _REFERENCE_FLOW_NAMES = ["bpf", "ffjord", "gf", "gmm", "maf", "nag", "nsf", "sospf", "unaf"]
 
@@ -26,10 +27,18 @@ def build_flow(name: str, input_features: int, output_features: int, hidden_laye
     return flow.to(device)
 
 
+def build_nn(input_features: int, output_features: int, hidden_layers: int, hidden_units: int, dropout: float = 0.0,
+             activation: str = "tanh", device=None) -> NNGenerator:
+    """build.py:49-77."""
+    transform = NNTransform(input_features=input_features, output_features=output_features, hidden_layers=hidden_layers,
+                            hidden_units=hidden_units, dropout=dropout, activation=activation)
+    return NNGenerator(input_features, transform).to(device)
+
+
 def build_generator(name: str, device: torch.device = None, **kws) -> GenerativeModel:
     """build.py:80-123."""
     if name == "nn":
-        raise NotImplementedError("the plain-MLP 'nn' generator is outside the hot-path scope (SURVEY.md §2 row 2)")
+        return build_nn(device=device, **kws)
     if name in _REFERENCE_FLOW_NAMES:
         return build_flow(name=name, device=device, **kws)
     raise ValueError(f"Invalid generative model name '{name}'")

@@ -117,6 +117,15 @@ class Problem:
     cfg: dict = field(default_factory=dict)
 
 
+def make_transforms_2d_nonlinear(num: int = 4, max_angle: float = 90.0, order: int = 3, max_strength: float = 1.5):
+    """rec_2d/nonlinear/setup.py:24-44: constant rotation, multipole strength swept over [-max, +max]."""
+    out = []
+    for strength in np.linspace(-max_strength, max_strength, num):
+        rotation = mfs.LinearTransform(mfs.rotation_matrix(np.radians(max_angle)).type(torch.float32))
+        out.append(mfs.CompositeTransform(mfs.MultipoleTransform(order=order, strength=float(strength)), rotation))
+    return out
+
+
 def build_problem(ndim: int = 6, num: int = 25, bins: int = 64, xmax: float = 4.0, seed: Optional[int] = 2,
                   transforms: int = 5, prior_scale: float = 1.0, device="cuda", dist_name: str = "rings",
                   dist_kws: Optional[dict] = None, meas_samples: int = 1_000_000, gen_name: str = "nsf",
@@ -134,6 +143,10 @@ def build_problem(ndim: int = 6, num: int = 25, bins: int = 64, xmax: float = 4.
         tfs = make_transforms_2d_linear(num)
         diag = mfd.Histogram1D(axis=0, edges=torch.linspace(-xmax, xmax, bins + 1), bandwidth=bandwidth, noise=True,
                                noise_scale=0.0, device=device, seed=seed)
+    elif optics == "2d_nonlinear":
+        tfs = make_transforms_2d_nonlinear(num)
+        diag = mfd.Histogram1D(axis=0, edges=torch.linspace(-xmax, xmax, bins + 1), bandwidth=bandwidth, noise=True,
+                               noise_scale=0.0, device=device, seed=seed)
     elif optics in ("nd_2d_corner", "nd_2d_random"):
         tfs = make_transforms_nd_2d_corner(ndim) if optics == "nd_2d_corner" else make_transforms_nd_2d_random(num, ndim, seed)
         e = [torch.linspace(-xmax, xmax, bins + 1), torch.linspace(-xmax, xmax, bins + 1)]
@@ -147,14 +160,19 @@ def build_problem(ndim: int = 6, num: int = 25, bins: int = 64, xmax: float = 4.
     x_true = get_distribution(dist_name, ndim=ndim, seed=seed, **kws).sample(meas_samples)
     tfs, diagnostics, measurements = generate_training_data(x_true, tfs, diag, device)
 
-    gen_kws = dict(input_features=ndim, output_features=ndim, hidden_layers=hidden_layers, hidden_units=hidden_units,
-                   transforms=transforms)
+    gen_kws = dict(input_features=ndim, output_features=ndim, hidden_layers=hidden_layers, hidden_units=hidden_units)
+    if gen_name == "nn":
+        gen_kws.update(dropout=0.0, activation="tanh")                    # config/gen/nn.yaml
+    else:
+        gen_kws["transforms"] = transforms
     if gen_name == "nsf":
         gen_kws["bins"] = spline_bins                                     # setup.py:120-121
     generator = build_generator(gen_name, device=device, **gen_kws)
     prior = mfp.Gaussian(ndim=ndim, scale=prior_scale, device=device)     # setup.py:133-135
     disc = {"kld": mfl.kl_divergence, "mae": mfl.mean_absolute_error, "mse": mfl.mean_square_error}[discrepancy]
-    model = MENTFlow(generator=generator, entropy_estimator=mfe.MonteCarloEntropyEstimator(prior=prior), prior=prior,
+    # config/model/nn.yaml: entropy_estimator "none" for the density-free NN generator (setup.py:137-141)
+    estimator = mfe.EmptyEntropyEstimator() if gen_name == "nn" else mfe.MonteCarloEntropyEstimator(prior=prior)
+    model = MENTFlow(generator=generator, entropy_estimator=estimator, prior=prior,
                      transforms=tfs, diagnostics=diagnostics, measurements=measurements,
                      penalty_parameter=penalty_parameter, discrepancy_function=disc)
     model = model.to(device)

@@ -216,6 +216,28 @@ class ProjKde2dFn(torch.autograd.Function):
         return gx, None, None, None, None, None, None, None, None
 
 
+class MultipoleKickFn(torch.autograd.Function):
+    """u = MultipoleTransform(order, strength, skew)(x)  (mentflow/simulate/transform.py:98-143)."""
+
+    @staticmethod
+    def forward(ctx, x, order: int, k: float, skew: bool):
+        x = _f32c(x)
+        u = torch.empty_like(x)
+        call("mf_multipole_kick_fwd", ptr(x), x.shape[0], x.shape[1], int(order), float(k), int(bool(skew)), ptr(u),
+             stream_ptr(x))
+        ctx.save_for_backward(x)
+        ctx.args = (int(order), float(k), int(bool(skew)))
+        return u
+
+    @staticmethod
+    def backward(ctx, gu):
+        (x,) = ctx.saved_tensors
+        order, k, skew = ctx.args
+        gx = torch.empty_like(x)
+        call("mf_multipole_kick_bwd", ptr(x), x.shape[0], x.shape[1], order, k, skew, ptr(_f32c(gu)), ptr(gx), stream_ptr(x))
+        return gx, None, None, None
+
+
 DISCREPANCY_KINDS = {"kld": 0, "mae": 1, "mse": 2}
 
 

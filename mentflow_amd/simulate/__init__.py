@@ -1,2 +1,2 @@
 from .simulate import forward, Simulator, group_measurements
-from .transform import LinearTransform, Transform, rotation_matrix
+from .transform import CompositeTransform, LinearTransform, MultipoleTransform, Transform, rotation_matrix

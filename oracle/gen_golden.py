@@ -273,5 +273,96 @@ def main():
               n=np.int64(20000))
 
 
+def main_nonlinear():
+    """Fixtures for the non-linear transport (MultipoleTransform / CompositeTransform, rec_2d/nonlinear) and for the
+    NN-generator configuration's loss (no entropy term, MAE discrepancy).  Separate RNG stream: running this does not
+    change the fixtures written by main()."""
+    import math
+    mf = _boot()
+    sys.modules.setdefault("scipy.special", __import__("scipy.special").special)
+    from mentflow.diagnostics import Histogram1D
+    from mentflow.simulate import LinearTransform, MultipoleTransform, CompositeTransform, forward, rotation_matrix
+    from mentflow.entropy import MonteCarloEntropyEstimator, EmptyEntropyEstimator
+    from mentflow.prior import Gaussian
+    from mentflow.loss import kl_divergence, mean_absolute_error
+    from mentflow.core import MENTFlow
+    from mentflow.generate import GenerativeModel
+
+    g = torch.Generator().manual_seed(20250621)
+    randn = lambda *s: torch.randn(*s, generator=g)
+
+    # ---- 11. the kick itself: values and vector-Jacobian products, d = 2, 4 and 6
+    out = {}
+    for d in (2, 4, 6):
+        x = randn(512, d) * 1.2
+        w = randn(512, d)
+        out[f"x_d{d}"], out[f"w_d{d}"] = _np(x), _np(w)
+        for order in (3, 4, 5):
+            for skew in (False, True):
+                xq = x.clone().requires_grad_(True)
+                t = MultipoleTransform(order=order, strength=0.7 * order, skew=skew)
+                u = t(xq)
+                (u * w).sum().backward()
+                tag = f"d{d}_o{order}_s{int(skew)}"
+                out[f"u_{tag}"], out[f"gx_{tag}"] = _np(u).copy(), _np(xq.grad)
+                # the reference's reverse_momentum (transform.py:18-21) flips momenta IN PLACE: hand it a copy
+                out[f"inv_{tag}"] = _np(t.inverse(u.detach().clone()))
+    _save("ref_multipole", **out)
+
+    # ---- 12. MENTFlow.loss through CompositeTransform(multipole, rotation): rec_2d/nonlinear (4 strengths, order 3)
+    class Injected(GenerativeModel):
+        def __init__(self, x, logp):
+            super().__init__()
+            self.x, self.logp = x, logp
+
+        def sample(self, n):
+            return self.x
+
+        def log_prob(self, x):
+            return self.logp
+
+        def sample_and_log_prob(self, n):
+            return self.x, self.logp
+
+    strengths = np.linspace(-1.5, 1.5, 4)
+    ts = []
+    for strength in strengths:
+        rot = LinearTransform(rotation_matrix(np.radians(90.0)).type(torch.float32))
+        ts.append(CompositeTransform(MultipoleTransform(order=3, strength=strength), rot))
+    dg = Histogram1D(axis=0, edges=torch.linspace(-4.5, 4.5, 86), bandwidth=0.5)
+    dgs = [[dg] for _ in ts]
+    xt = randn(20000, 2)
+    dg.kde = False
+    meas = forward(xt, ts, dgs)
+    dg.kde = True
+    for i in range(len(meas)):
+        mm = meas[i][0]
+        meas[i][0] = mm / torch.sum(mm) / (dg.edges[1] - dg.edges[0])
+    n = 2048
+    xin, lpin = randn(n, 2) * 1.1, randn(n) - 1.0
+    res = {}
+    for tag, ent, disc, mu in (("flow", "mc", kl_divergence, 500.0), ("nn", "none", mean_absolute_error, 500.0)):
+        xq = xin.clone().requires_grad_(True)
+        lq = lpin.clone().requires_grad_(True)
+        prior = Gaussian(ndim=2, scale=1.0)
+        est = MonteCarloEntropyEstimator(prior=prior) if ent == "mc" else EmptyEntropyEstimator()
+        model = MENTFlow(transforms=ts, diagnostics=dgs, measurements=meas,
+                         generator=Injected(xq, lq if ent == "mc" else None), prior=prior,
+                         entropy_estimator=est, discrepancy_function=disc, penalty_parameter=mu)
+        L, H, D = model.loss(n)
+        L.backward()
+        res[f"L_{tag}"], res[f"H_{tag}"] = _np(L), np.float32(float(H))
+        res[f"D_{tag}"] = np.array([float(v) for v in D], dtype=np.float32)
+        res[f"gx_{tag}"] = _np(xq.grad)
+        if ent == "mc":
+            res[f"glogp_{tag}"] = _np(lq.grad)
+    _save("ref_mentflow_loss_2d_nonlinear", x=_np(xin), log_prob=_np(lpin), strengths=strengths.astype(np.float64),
+          angle_deg=np.float64(90.0), order=np.int64(3), edges=_np(dg.edges),
+          measurements=np.stack([_np(m[0]) for m in meas]), **res)
+
+
 if __name__ == "__main__":
-    main()
+    if "--nonlinear" in sys.argv:
+        main_nonlinear()
+    else:
+        main()

@@ -24,7 +24,17 @@ def flow_spec_from_generator(generator, dtype=torch.float32) -> of.FlowSpec:
 
 def oracle_problem(prob, dtype=torch.float32):
     spec = flow_spec_from_generator(prob.model.generator, dtype)
-    transforms = [om.LinearTransform(t.matrix.detach().cpu().to(dtype)) for t in prob.transforms]
+    def restate(t):
+        kind = type(t).__name__
+        if kind == "LinearTransform":
+            return om.LinearTransform(t.matrix.detach().cpu().to(dtype))
+        if kind == "MultipoleTransform":
+            return om.MultipoleTransform(t.order, t.strength, t.skew)
+        if kind == "CompositeTransform":
+            return om.CompositeTransform(*[restate(c) for c in t.transforms])
+        raise TypeError(kind)
+
+    transforms = [restate(t) for t in prob.transforms]
     d0 = prob.diagnostics[0][0]
     if d0.ndim == 1:
         diag = om.Histogram1D(edges=d0.edges.cpu().to(dtype), bandwidth=d0.bandwidth_bins, axis=d0.axis)

@@ -29,6 +29,59 @@ class LinearTransform:
         return torch.matmul(u, self.matrix_inv.T)                 # :70-71
 
 
+class MultipoleTransform:
+    """mentflow/simulate/transform.py:78-146 (orders 3..5 are the ones that do not raise; note U[:,3] reads X[:,1])."""
+
+    def __init__(self, order: int, strength: float, skew: bool = False) -> None:
+        self.order, self.strength, self.skew = int(order), float(strength), bool(skew)
+
+    def __call__(self, X: torch.Tensor) -> torch.Tensor:
+        import math
+        U = X.clone()
+        x = X[:, 0]
+        y = X[:, 2] if X.shape[1] > 2 else 0.0 * X[:, 0]
+        if self.order == 3:
+            re, im = x ** 2 - y ** 2, 2.0 * x * y
+        elif self.order == 4:
+            re, im = x ** 3 - 3.0 * y ** 2 * x, -y ** 3 + 3.0 * x ** 2 * y
+        elif self.order == 5:
+            re, im = x ** 4 - 6.0 * x ** 2 * y ** 2 + y ** 4, 4.0 * x ** 3 * y - 4.0 * x * y ** 3
+        else:
+            raise ValueError("MPS-compatible MultipoleTransform requires order <= 5.")
+        k = self.strength / math.factorial(self.order - 1)
+        if self.skew:
+            U[:, 1] = X[:, 1] + k * im
+            if X.shape[1] > 2:
+                U[:, 3] = X[:, 3] + k * re
+        else:
+            U[:, 1] = X[:, 1] - k * re
+            if X.shape[1] > 2:
+                U[:, 3] = X[:, 1] + k * im
+        return U
+
+
+class CompositeTransform:
+    """transform.py:35-55."""
+
+    def __init__(self, *transforms) -> None:
+        self.transforms = list(transforms)
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+
+def make_transforms_2d_nonlinear(num: int = 4, max_angle: float = 90.0, order: int = 3, max_strength: float = 1.5):
+    """experiments/rec_2d/nonlinear/setup.py:24-44."""
+    import numpy as np
+    out = []
+    for strength in np.linspace(-max_strength, max_strength, num):
+        rot = LinearTransform(rotation_matrix(np.radians(max_angle)).type(torch.float32))
+        out.append(CompositeTransform(MultipoleTransform(order, float(strength)), rot))
+    return out
+
+
 def simulate_forward(x, transforms, diagnostics) -> List[List[torch.Tensor]]:
     """mentflow/simulate/simulate.py:8-33."""
     predictions = []
@@ -148,7 +201,10 @@ def unravel(iterable):
 def mentflow_loss(x, log_prob, transforms, diagnostics, measurements, prior, penalty_parameter,
                   discrepancy_function: Callable = kl_divergence):
     """mentflow/core.py:84-117 with (x, log_prob) injected: returns (L, H, [D_p])."""
-    H = mc_entropy(x, log_prob, prior)                                         # :84-87
+    if log_prob is None:                                                       # entropy.py:21-26 (EmptyEntropyEstimator)
+        H = torch.zeros((), dtype=x.dtype)
+    else:
+        H = mc_entropy(x, log_prob, prior)                                     # :84-87
     predictions = simulate_forward(x, transforms, diagnostics)                 # :114
     D = [discrepancy_function(pred, meas)                                      # :89-93
          for pred, meas in zip(unravel(predictions), unravel(measurements))]

@@ -71,8 +71,8 @@ def test_unsupported_pieces_raise():
     with pytest.raises(ValueError):
         mf.generate.build_generator("not-a-flow", input_features=2, output_features=2, hidden_layers=3, hidden_units=64,
                                     transforms=1)
-    with pytest.raises(NotImplementedError):
-        mf.generate.build_generator("nn", input_features=2, output_features=2, hidden_layers=3, hidden_units=64)
+    nn_gen = mf.generate.build_generator("nn", input_features=2, output_features=2, hidden_layers=3, hidden_units=64)
+    assert nn_gen.log_prob(None) is None and nn_gen.sample_and_log_prob(5)[0].shape == (5, 2)
     with pytest.raises(NotImplementedError):
         mf.generate.build_generator("nsf", input_features=2, output_features=2, hidden_layers=3, hidden_units=50,
                                     transforms=1)

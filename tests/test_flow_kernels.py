@@ -27,7 +27,7 @@ def make_generator(backend, d, kind="nsf", transforms=2, bins=20, steep=True, se
     return gen.to(backend)
 
 
-@pytest.mark.parametrize("d,bins", [(6, 20), (2, 20), (3, 8)])
+@pytest.mark.parametrize("d,bins", [(6, 20), (2, 20), (3, 8), (4, 20), (5, 8), (7, 20)])
 def test_nsf_forward_matches_oracle(backend, d, bins):
     gen = make_generator(backend, d, bins=bins)
     torch.manual_seed(1)
@@ -49,7 +49,7 @@ def test_nsf_forward_matches_oracle(backend, d, bins):
     assert (x32 - x64).abs().max() < 5e-5 and (lp32 - lp64).abs().max() < 5e-4
 
 
-@pytest.mark.parametrize("d", [6, 2])
+@pytest.mark.parametrize("d", [6, 2, 4, 7])
 def test_nsf_backward_matches_oracle(backend, d):
     gen = make_generator(backend, d)
     torch.manual_seed(2)
@@ -108,6 +108,65 @@ def test_full_train_step_matches_oracle(backend):
     assert abs(float(H) - float(Ho)) < 1e-4
     assert (torch.stack(D).cpu() - torch.stack(Do)).abs().max() < 2e-6 + 2e-4 * float(torch.stack(Do).abs().max())
     assert abs(float(L) - float(Lo)) < 1e-4 + 500 * 2e-6
+    assert (g.double() - go).abs().max() < 2e-3 * go.abs().max()
+
+
+def test_nonlinear_train_step_matches_oracle(backend):
+    """rec_2d/nonlinear (experiments/config/rec_2d_nonlinear_flow.yaml): 2-D NSF -> multipole kick -> rotation ->
+    KDE -> loss, forward and backward through mf_multipole_kick_bwd and the flow backward, vs the fp64 oracle."""
+    from mentflow_amd.harness import build_problem
+    prob = build_problem(ndim=2, num=4, bins=85, xmax=4.5, seed=21, transforms=2, prior_scale=1.0, device=backend,
+                         meas_samples=20000, penalty_parameter=500.0, optics="2d_nonlinear")
+    n = 200
+    torch.manual_seed(6)
+    z = torch.randn(n, 2)
+    prob.model.generator.inject_z = z.to(backend)
+    L, H, D = prob.model.loss(n)
+    L.backward()
+    g = torch.cat([p.grad.reshape(-1) for p in prob.model.parameters()]).cpu()
+    Lo, Ho, Do, go = oracle_step(prob, z, torch.float64)
+    assert abs(float(H) - float(Ho)) < 1e-4
+    assert (torch.stack(D).cpu() - torch.stack(Do)).abs().max() < 2e-6 + 2e-4 * float(torch.stack(Do).abs().max())
+    assert abs(float(L) - float(Lo)) < 1e-4 + 500 * 2e-6 + 2e-5 * abs(float(Lo))
+    assert (g.double() - go).abs().max() < 2e-3 * go.abs().max()
+
+
+def test_nn_generator_train_step_matches_oracle(backend):
+    """The paper's NN baseline (generate/nn.py + config rec_2d_nonlinear_nn.yaml): plain MLP generator without a
+    density, EmptyEntropyEstimator, MAE discrepancy; its samples go through the same kick / projection / KDE /
+    discrepancy kernels.  Oracle: the same torch modules in fp64 on the CPU + oracle.model.mentflow_loss."""
+    import copy
+    from mentflow_amd.harness import build_problem
+    from oracle.harness import oracle_problem
+    from oracle import model as om
+    prob = build_problem(ndim=2, num=4, bins=85, xmax=4.5, seed=21, prior_scale=1.0, device=backend, meas_samples=20000,
+                         penalty_parameter=500.0, optics="2d_nonlinear", gen_name="nn", hidden_layers=3, hidden_units=50,
+                         discrepancy="mae")
+    gen = prob.model.generator
+    assert isinstance(gen, mf.generate.NNGenerator) and isinstance(prob.model.entropy_estimator, mf.entropy.EmptyEntropyEstimator)
+    n = 300
+    torch.manual_seed(8)
+    z = torch.randn(n, 2)
+    gen.inject_z = z.to(backend)
+    L, H, D = prob.model.loss(n)
+    L.backward()
+    g = torch.cat([p.grad.reshape(-1) for p in prob.model.parameters()]).cpu()
+    assert float(H) == 0.0
+    net = copy.deepcopy(gen.transform).cpu().double()
+    for p in net.parameters():
+        p.grad = None
+    prob.cfg["gen_name"] = "nn"
+    tfs = [om.CompositeTransform(om.MultipoleTransform(t.transforms[0].order, t.transforms[0].strength),
+                                 om.LinearTransform(t.transforms[1].matrix.cpu().double())) for t in prob.transforms]
+    d0 = prob.diagnostics[0][0]
+    diag = om.Histogram1D(edges=d0.edges.cpu().double(), bandwidth=d0.bandwidth_bins, axis=0)
+    meas = [[m.cpu().double() for m in row] for row in prob.measurements]
+    Lo, Ho, Do = om.mentflow_loss(net(z.double()), None, tfs, [[diag] for _ in tfs], meas, None, 500.0,
+                                  om.mean_absolute_error)
+    Lo.backward()
+    go = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert (torch.stack(D).cpu() - torch.stack(Do).detach()).abs().max() < 2e-6 + 2e-4 * float(torch.stack(Do).abs().max())
+    assert abs(float(L) - float(Lo)) < 1e-4 + 2e-5 * abs(float(Lo))
     assert (g.double() - go).abs().max() < 2e-3 * go.abs().max()
 
 

@@ -153,3 +153,56 @@ def test_mentflow_loss_nd_2d_corner(backend):
     e = torch.linspace(-3.5, 3.5, 49)
     diag = mf.diagnostics.Histogram2D(axis=(0, 2), edges=(e, e), bandwidth=(0.5, 0.5)).to(backend)
     _loss_case(backend, g, transforms, [[diag] for _ in transforms], 6)
+
+
+@pytest.mark.parametrize("d", [2, 4, 6])
+def test_multipole_kick_vs_reference(backend, d):
+    """mf_multipole_kick_fwd/bwd against the reference's MultipoleTransform outputs and autograd gradients.
+    fp32: the kernel evaluates z^(order-1) by complex multiplication, the reference by the expanded polynomial, so
+    the two differ by rounding only: rtol 1e-5, atol 1e-5 * max|value|."""
+    g = load_golden("ref_multipole")
+    for order in (3, 4, 5):
+        for skew in (False, True):
+            tag = f"d{d}_o{order}_s{int(skew)}"
+            x = g[f"x_d{d}"].to(backend).clone().requires_grad_(True)
+            t = mf.simulate.MultipoleTransform(order, 0.7 * order, skew)
+            u = t(x)
+            (u * g[f"w_d{d}"].to(backend)).sum().backward()
+            close(u, g[f"u_{tag}"], 1e-5, 1e-5 * float(g[f"u_{tag}"].abs().max()))
+            close(x.grad, g[f"gx_{tag}"], 1e-5, 1e-5 * float(g[f"gx_{tag}"].abs().max()))
+            close(t.inverse(u.detach()), g[f"inv_{tag}"], 1e-5, 1e-5 * float(g[f"inv_{tag}"].abs().max()))
+    with pytest.raises(ValueError):
+        mf.simulate.MultipoleTransform(2, 1.0)
+
+
+def test_mentflow_loss_2d_nonlinear(backend):
+    """rec_2d/nonlinear (4 x CompositeTransform(multipole, rotation), 85 bins, xmax 4.5) in the flow configuration
+    (MC entropy + KL) and the NN configuration (EmptyEntropyEstimator + MAE, log_prob None)."""
+    g = load_golden("ref_mentflow_loss_2d_nonlinear")
+    rot = mf.simulate.rotation_matrix(np.radians(float(g["angle_deg"]))).type(torch.float32)
+    transforms = [mf.simulate.CompositeTransform(mf.simulate.MultipoleTransform(int(g["order"]), float(s)),
+                                                 mf.simulate.LinearTransform(rot)).to(backend)
+                  for s in g["strengths"]]
+    diag = mf.diagnostics.Histogram1D(edges=g["edges"], bandwidth=0.5, axis=0).to(backend)
+    meas = [[m.to(backend)] for m in g["measurements"]]
+    for tag in ("flow", "nn"):
+        x = g["x"].to(backend).clone().requires_grad_(True)
+        lp = g["log_prob"].to(backend).clone().requires_grad_(True) if tag == "flow" else None
+        prior = mf.prior.Gaussian(2, 1.0)
+        est = mf.entropy.MonteCarloEntropyEstimator(prior=prior) if tag == "flow" else mf.entropy.EmptyEntropyEstimator()
+        disc = mf.loss.kl_divergence if tag == "flow" else mf.loss.mean_absolute_error
+        model = mf.MENTFlow(transforms=transforms, diagnostics=[[diag] for _ in transforms], measurements=meas,
+                            generator=Injected(x, lp), prior=prior, entropy_estimator=est, discrepancy_function=disc,
+                            penalty_parameter=500.0)
+        L, H, D = model.loss(x.shape[0])
+        L.backward()
+        close(torch.stack(D), g[f"D_{tag}"], 2e-4, 1e-7)
+        close(torch.as_tensor(float(H)), g[f"H_{tag}"], 1e-5, 1e-6)
+        close(L, g[f"L_{tag}"], 2e-5, 1e-5 + 500 * 1e-6)
+        gmax = float(g[f"gx_{tag}"].abs().max())
+        close(x.grad, g[f"gx_{tag}"], 1e-3, 2e-5 * gmax)
+        if lp is not None:
+            close(lp.grad, g[f"glogp_{tag}"], 1e-6, 1e-9)
+    # the un-fused list API gives the same predictions
+    preds = mf.simulate.forward(g["x"].to(backend), transforms, [[diag] for _ in transforms])
+    assert len(preds) == 4 and all(len(p) == 1 and p[0].shape == (85,) for p in preds)
