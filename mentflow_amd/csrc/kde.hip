@@ -239,10 +239,12 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ 2-D backward
-// A workgroup owns KDE2D_BWD_NPT * 256 particles and walks the projection groups once: the gS images of a group are
-// staged into LDS one time per workgroup (not once per 256 particles), every thread adds the group's contribution to
-// the gx rows of its own particles (thread-private read-modify-write, no atomics).
-constexpr int KDE2D_BWD_NPT = 16;
+// A workgroup owns KDE2D_BWD_NPT * 256 particles and walks the projection groups once.  Every thread keeps the rows and
+// the gradient rows of its KDE2D_BWD_NPT particles in registers for the whole walk (no read-modify-write of gx per
+// group); the gS images of a group are staged into LDS once per workgroup and group.  The group size is chosen so that
+// the image stays under ~40 KB (one 85 x 85 image): several workgroups then share a CU and hide the latency of the
+// data-dependent LDS reads (one workgroup per CU with five images was 2.7x slower).
+constexpr int KDE2D_BWD_NPT = 4;
 __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V0, const float* __restrict__ V1, int P,
     int Pg, const float* __restrict__ coords_x, int Bx, float inv_sx, int Rx, const float* __restrict__ coords_y,
@@ -260,6 +262,14 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
     const float cx0 = cxl[0], inv_dx = 1.0f / (cxl[1] - cxl[0]);
     const float cy0 = cyl[0], inv_dy = 1.0f / (cyl[1] - cyl[0]);
     const int64_t base = (int64_t)blockIdx.x * KDE_BLOCK * KDE2D_BWD_NPT + threadIdx.x;
+    float xv[KDE2D_BWD_NPT][KDE_DMAX], gv[KDE2D_BWD_NPT][KDE_DMAX];
+#pragma unroll
+    for (int t = 0; t < KDE2D_BWD_NPT; ++t) {
+        const int64_t p = base + (int64_t)t * KDE_BLOCK;
+        load_row(x, p < n ? p : n - 1, d, xv[t]);
+#pragma unroll
+        for (int j = 0; j < KDE_DMAX; ++j) gv[t][j] = 0.0f;
+    }
     for (int p_begin = 0; p_begin < P; p_begin += Pg) {
         const int np = min(Pg, P - p_begin);
         __syncthreads();
@@ -269,16 +279,11 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
             V1l[i] = V1[p_begin * d + i];
         }
         __syncthreads();
-        for (int t = 0; t < KDE2D_BWD_NPT; ++t) {
-            const int64_t p = base + (int64_t)t * KDE_BLOCK;
-            if (p >= n) break;
-            float xv[KDE_DMAX], gv[KDE_DMAX];
-            load_row(x, p, d, xv);
 #pragma unroll
-            for (int j = 0; j < KDE_DMAX; ++j) gv[j] = 0.0f;
+        for (int t = 0; t < KDE2D_BWD_NPT; ++t) {
             for (int q = 0; q < np; ++q) {
-                const float u0 = project(xv, V0l + q * d, d);
-                const float u1 = project(xv, V1l + q * d, d);
+                const float u0 = project(xv[t], V0l + q * d, d);
+                const float u1 = project(xv[t], V1l + q * d, d);
                 const int ka = centre_bin(u0, cx0, inv_dx, Bx, Rx);
                 const int kb = centre_bin(u1, cy0, inv_dy, By, Ry);
                 float wy[2 * KDE_RMAX2D + 1], dy[2 * KDE_RMAX2D + 1];
@@ -317,12 +322,17 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
                 }
 #pragma unroll
                 for (int j = 0; j < KDE_DMAX; ++j)
-                    if (j < d) gv[j] = fmaf(du0, V0l[q * d + j], fmaf(du1, V1l[q * d + j], gv[j]));
+                    if (j < d) gv[t][j] = fmaf(du0, V0l[q * d + j], fmaf(du1, V1l[q * d + j], gv[t][j]));
             }
-            const bool add = accumulate || p_begin > 0;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < KDE2D_BWD_NPT; ++t) {
+        const int64_t p = base + (int64_t)t * KDE_BLOCK;
+        if (p < n) {
 #pragma unroll
             for (int j = 0; j < KDE_DMAX; ++j)
-                if (j < d) gx[p * d + j] = add ? gx[p * d + j] + gv[j] : gv[j];
+                if (j < d) gx[p * d + j] = accumulate ? gx[p * d + j] + gv[t][j] : gv[t][j];
         }
     }
 }
@@ -672,12 +682,14 @@ extern "C" int mf_proj_kde1d_bwd(const float* x, int64_t n, int d, const float* 
     return check_launch("mf_proj_kde1d_bwd");
 }
 
-static int kde2d_geometry(int d, int P, int Bx, int By, int rx, int ry, int* Pg, size_t* smem, int extra) {
+static int kde2d_geometry(int d, int P, int Bx, int By, int rx, int ry, int* Pg, size_t* smem, int extra,
+                          int budget_floats = KDE_LDS_FLOATS) {
     if (rx > KDE_RMAX2D || ry > KDE_RMAX2D)
         return fail("2-D KDE kernel supports a truncation radius <= %d bins (bandwidth <= 0.6 bin widths)", KDE_RMAX2D);
     const int BB = Bx * By;
     if (BB > KDE_LDS_FLOATS) return fail("2-D histogram image %dx%d exceeds the LDS budget", Bx, By);
-    int g = KDE_LDS_FLOATS / BB;
+    int g = budget_floats / BB;
+    if (g < 1) g = 1;
     if (g > P) g = P;
     *Pg = g;
     *smem = sizeof(float) * ((size_t)g * BB + 2 * (size_t)g * d + Bx + By + extra);
@@ -691,8 +703,11 @@ extern "C" int mf_proj_kde2d_fwd(const float* x, int64_t n, int d, const float* 
     if (radius_x > KDE_RMAX2D || radius_y > KDE_RMAX2D)
         return fail("2-D KDE kernel supports a truncation radius <= %d bins (bandwidth <= 0.6 bin widths)", KDE_RMAX2D);
     const int BB = Bx * By;
-    const int budget = 18432;                         // 144 KiB of 64-bit bins
-    if (BB > budget) return fail("2-D histogram image %dx%d exceeds the LDS budget", Bx, By);
+    const int budget_max = 18432;                     // 144 KiB of 64-bit bins
+    if (BB > budget_max) return fail("2-D histogram image %dx%d exceeds the LDS budget", Bx, By);
+    // images per workgroup: ~72 KiB, so that two workgroups share a CU
+    static const int fwd_budget = [] { const char* e = getenv("MENTFLOW_KDE2D_FWD_BINS"); return e ? atoi(e) : 9216; }();
+    const int budget = fwd_budget > BB ? (fwd_budget > budget_max ? budget_max : fwd_budget) : BB;
     double* Sfix = reinterpret_cast<double*>(ws);
     if (hipMemsetAsync(Sfix, 0, sizeof(double) * (size_t)P * BB, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
     if (n > 0) {
@@ -719,7 +734,9 @@ extern "C" int mf_proj_kde2d_bwd(const float* x, int64_t n, int d, const float* 
     if (kde_check(n, d, P, Bx) || kde_check(n, d, P, By)) return 1;
     int Pg;
     size_t smem;
-    if (kde2d_geometry(d, P, Bx, By, radius_x, radius_y, &Pg, &smem, 0)) return 1;
+    // ~40 KB of images per workgroup: four workgroups per CU (see the kernel's header comment)
+    static const int bwd_budget = [] { const char* e = getenv("MENTFLOW_KDE2D_BWD_FLOATS"); return e ? atoi(e) : 10240; }();
+    if (kde2d_geometry(d, P, Bx, By, radius_x, radius_y, &Pg, &smem, 0, bwd_budget)) return 1;
     if (n == 0) return 0;
     const int64_t per_wg = (int64_t)KDE_BLOCK * KDE2D_BWD_NPT;
     const int64_t G = (n + per_wg - 1) / per_wg;

@@ -49,11 +49,16 @@ def test_nsf_forward_matches_oracle(backend, d, bins):
     assert (x32 - x64).abs().max() < 5e-5 and (lp32 - lp64).abs().max() < 5e-4
 
 
+@pytest.mark.parametrize("variant", ["two-kernel", "fused"])
 @pytest.mark.parametrize("d", [6, 2, 4, 7])
-def test_nsf_backward_matches_oracle(backend, d):
+def test_nsf_backward_matches_oracle(backend, d, variant, monkeypatch):
+    """variant "fused": rqs_layer_bwd_fused_kernel (opt-in, parameter gradients inside the backward kernel, operands
+    transposed through LDS; d = 7 does not fit its LDS budget and silently takes the two-kernel path);
+    n = 300 spans three 4-tile groups with a ragged last tile."""
+    monkeypatch.setenv("MENTFLOW_BWD_FUSED", "1" if variant == "fused" else "0")
     gen = make_generator(backend, d)
     torch.manual_seed(2)
-    n = 70
+    n = 70 if variant == "two-kernel" else 300
     z = torch.randn(n, d) * 1.5
     wx, wl = torch.randn(n, d), torch.randn(n)
     x, lp = gen.sample_and_log_prob(n, z=z.to(backend))

@@ -1,0 +1,36 @@
+"""Development tool: builds a -DMF_WS_DIAG copy of the library, runs the fused backward and prints where wave 0 of
+every workgroup spends its time (s_memtime stamps, 100 MHz)."""
+import ctypes, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "mentflow_amd", "csrc")
+lib = os.path.join(ROOT, "gpurun_out", "libmentflow_diag.so")
+os.makedirs(os.path.dirname(lib), exist_ok=True)
+extra = os.environ.get("WS_DIAG_FLAGS", "").split()
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMF_WS_DIAG", *extra,
+                os.path.join(csrc, "api.hip"), os.path.join(csrc, "kde.hip"), os.path.join(csrc, "flow.hip"), "-o", lib], check=True)
+import torch
+from mentflow_amd import _lib
+_lib.use_library(lib)
+import mentflow_amd as mf
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+gen = mf.generate.build_generator("nsf", device=dev, input_features=6, output_features=6, hidden_layers=3, hidden_units=64, transforms=1, bins=20)
+n = 1 << 20
+z = torch.randn(n, 6, device=dev)
+for it in range(2):
+    gen.zero_grad()
+    x, lp = gen.sample_and_log_prob(n, z=z)
+    (x.sum() / n + lp.mean()).backward()
+torch.cuda.synchronize()
+raw = (ctypes.c_ulonglong * (256 * 16))()
+h = ctypes.CDLL(lib)
+assert h.mf_debug_ws_read(raw) == 0
+a = np.array(raw, dtype=np.float64).reshape(256, 16)
+groups = (n // 32) / 4 / 256
+names = ["trunk fwd", "phi = W3 h (x d)", "rqs_apply (x d)", "barrier A (x d)", "stage gv (x d)", "barrier B (x d)",
+         "dW last layer (x d)", "rotate acc (x d)", "gh += W3^T gv (x d)", "trunk bwd + dW", "gx", "TOTAL"]
+print("groups per workgroup:", groups, " (ticks of s_memtime, 100 MHz: x21 for 2.1 GHz cycles)")
+for q, nm in enumerate(names):
+    print(f"  {nm:24s} {a[:, q].mean() / groups:9.1f} ticks per group   {100 * a[:, q].mean() / a[:, 11].mean():5.1f} %")
