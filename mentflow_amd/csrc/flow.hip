@@ -697,7 +697,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                                                                         const float* __restrict__ gy,
                                                                         const float* __restrict__ glogp,
                                                                         float* __restrict__ gx, float* __restrict__ gimage,
-                                                                        Sparsity sp, int dbg) {
+                                                                        Sparsity sp) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
     // ---- stage the image: trunk as is, last-layer blocks compacted to their non-zero columns
@@ -804,7 +804,6 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             WS_ACC(c_[2], t0_);
 #pragma unroll
             for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
-            if (!(dbg & 2)) {
             t0_ = WS_T();
             if (i > 0) __syncthreads();                    // product i-1 has read S_A
             WS_ACC(c_[3], t0_);
@@ -814,13 +813,12 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             t0_ = WS_T();
             __syncthreads();
             WS_ACC(c_[5], t0_);
-            }
             t0_ = WS_T();
             {
                 const bool full = sp.rt1[i] != 0;
                 const int ra = full ? fra : hra, rb = full ? frb : 0;
                 const int t0 = full ? 0 : ht0, t1 = full ? 2 : 1;
-                const bool mm = sp.kend3[i] > 0 && !(dbg & 1), bias = rb == 0 && !(dbg & 1);
+                const bool mm = sp.kend3[i] > 0, bias = rb == 0;
                 // the accumulator of the current feature is always accO[0]: the array is rotated by one after every
                 // feature (register moves) instead of being indexed by the runtime feature number
                 dw_accum(SA, SB, ra, rb, t0, t1, mm, bias, lane, accO[0], bsO[0]);
@@ -934,10 +932,10 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
 }
 
 // =========================================================================================== backward, RQS, wave-specialised
-// Measured on MI355X (tools/ubench_mfma_valu.hip): a wave that only issues fp32 MFMAs and a wave that only issues VALU
-// work co-execute on one SIMD at full rate, but waves that each mix the two run at the SUM of both times (even when the
-// instructions are interleaved 1:16 in one stream).  The generic backward kernel above is such a mix (conditioner GEMMs
-// + spline adjoint in every wave): 45 % MFMA-busy + 35 % VALU-active, no overlap.
+// Built on a mis-read measurement (tools/ubench_mfma_valu.hip had its MFMA-only and VALU-only waves on different SIMDs):
+// the corrected one (tools/ubench_mfma_valu2.hip) shows that on gfx950 fp32 MFMAs and VALU work do NOT
+// overlap on a SIMD, whichever waves issue them — time is the SUM of both — so splitting the roles cannot win.  Kept
+// opt-in (MENTFLOW_BWD_WS=1) as the measured negative result: 15.8 ms against 11.2 ms for the generic kernel.
 //
 // Here the workgroup's 8 waves form 4 pairs; waves w and w+4 share a SIMD.  Wave w (< 4) is the MATRIX wave of pair w:
 // trunk recompute, output blocks phi_i = W3_i h3, gh += W3_i^T gphi_i, trunk backward, activation / pre-activation
@@ -1729,14 +1727,12 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
             if (smem_f <= 160 * 1024) {
                 const int64_t ngroups = ((n + 31) / 32 + 3) / 4;
                 const int gf = (int)(ngroups > NUM_CU ? NUM_CU : ngroups);
-                const char* de = getenv("MENTFLOW_FB_DBG");
-                const int dbg = de ? atoi(de) : 0;
 #define XF(KK, LL)                                                                                                    \
     if (!launched && bins == KK && hidden_layers == LL) {                                                             \
         ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
         MF_ALLOW_DYN_SMEM((rqs_layer_bwd_fused_kernel<KK, LL>), smem_f);                                              \
         MF_LAUNCH((rqs_layer_bwd_fused_kernel<KK, LL>), gf, FB_BLOCK, smem_f, stream, image, d, x, n, gy, glogp, gx,   \
-                  gimage, sp, dbg);                                                                                      \
+                  gimage, sp);                                                                                           \
         launched = true;                                                                                              \
     }
                 MF_RQS_CASES(XF)

@@ -1,4 +1,6 @@
 // Micro-benchmark (development tool): do v_mfma_f32_32x32x2_f32 and fp32 VALU work co-execute on a gfx950 SIMD?
+// SUPERSEDED by ubench_mfma_valu2.hip: mode 2 below (even waves MFMA / odd waves VALU) puts the two kinds on DIFFERENT
+// SIMDs (wave w runs on SIMD w % 4), so its "full rate" result says nothing about co-execution on one SIMD.
 // Each wave runs a chain of fp32 MFMAs, or a chain of v_fma_f32, or both interleaved; 4 or 8 waves per CU-SIMD mixes.
 #include <hip/hip_runtime.h>
 #include <cstdio>
