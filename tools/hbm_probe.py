@@ -11,7 +11,7 @@ def timeit(f, reps=5):
     for _ in range(reps): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-t = timeit(lambda: a.sum()); print(f"read  (sum)      : {4 * n / t / 1e9:8.0f} GB/s")
-t = timeit(lambda: b.fill_(1.0)); print(f"write (fill)     : {4 * n / t / 1e9:8.0f} GB/s")
-t = timeit(lambda: b.copy_(a)); print(f"copy  (r+w)      : {8 * n / t / 1e9:8.0f} GB/s")
-t = timeit(lambda: torch.add(a, 1.0, out=b)); print(f"add   (r+w)      : {8 * n / t / 1e9:8.0f} GB/s")
+t = timeit(lambda: a.sum()); print(f"read  (sum)      : {4 * n / t / 1e6:8.0f} GB/s")
+t = timeit(lambda: b.fill_(1.0)); print(f"write (fill)     : {4 * n / t / 1e6:8.0f} GB/s")
+t = timeit(lambda: b.copy_(a)); print(f"copy  (r+w)      : {8 * n / t / 1e6:8.0f} GB/s")
+t = timeit(lambda: torch.add(a, 1.0, out=b)); print(f"add   (r+w)      : {8 * n / t / 1e6:8.0f} GB/s")
