@@ -128,11 +128,14 @@ __global__ __launch_bounds__(KDE_BLOCK) void acc_to_float_kernel(const double* _
 }
 
 // ------------------------------------------------------------------------------------------------ 1-D backward
-// grid (G); loops over projection groups; LDS: [Pg*B] gS | [Pg*d] V | [B] coords
+// grid (G); loops over projection groups; LDS: [Pg*B] gS | [Pg*d] V | [B] coords.
+// CH (1, 2, 4 or 8) adjacent lanes share a particle and take every CH-th projection; their partial gradient rows are
+// summed with a fixed butterfly (deterministic, no atomics).  Small batches use CH > 1: one lane per particle walks
+// all P projections serially, which leaves most of the chip idle at the reference's 25 000-particle batch.
 __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V, int P, int Pg,
     const float* __restrict__ coords, int B, float inv_sigma, int R, const float* __restrict__ gS,
-    float* __restrict__ gx, int accumulate) {
+    float* __restrict__ gx, int accumulate, int CH) {
     MF_DYN_SMEM(float, lds);
     float* img = lds;
     float* Vl = img + Pg * B;
@@ -141,7 +144,9 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
     __syncthreads();
     const float c0 = cl[0];
     const float inv_delta = 1.0f / (cl[1] - cl[0]);
-    const int64_t p = (int64_t)blockIdx.x * KDE_BLOCK + threadIdx.x;
+    const int per_wg = KDE_BLOCK / CH;
+    const int chunk = threadIdx.x % CH;
+    const int64_t p = (int64_t)blockIdx.x * per_wg + threadIdx.x / CH;
     const bool valid = p < n;
     float xv[KDE_DMAX], gv[KDE_DMAX];
     load_row(x, valid ? p : 0, d, xv);
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
         for (int i = threadIdx.x; i < np * B; i += KDE_BLOCK) img[i] = gS[(int64_t)p_begin * B + i];
         for (int i = threadIdx.x; i < np * d; i += KDE_BLOCK) Vl[i] = V[p_begin * d + i];
         __syncthreads();
-        for (int q = 0; q < np; ++q) {
+        for (int q = chunk; q < np; q += CH) {
             const float u = project(xv, Vl + q * d, d);
             const int kc = centre_bin(u, c0, inv_delta, B, R);
             float du = 0.0f;
@@ -169,7 +174,11 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
                 if (j < d) gv[j] = fmaf(du, Vl[q * d + j], gv[j]);
         }
     }
-    if (valid) {
+    for (int m = 1; m < CH; m <<= 1) {
+#pragma unroll
+        for (int j = 0; j < KDE_DMAX; ++j) gv[j] += __shfl_xor(gv[j], m);
+    }
+    if (valid && chunk == 0) {
 #pragma unroll
         for (int j = 0; j < KDE_DMAX; ++j)
             if (j < d) gx[p * d + j] = accumulate ? gx[p * d + j] + gv[j] : gv[j];
@@ -645,7 +654,16 @@ extern "C" int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* 
     if (hipMemsetAsync(Sfix, 0, sizeof(double) * (size_t)P * B, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
     if (n > 0) {
         const int R = radius < 0 ? 0 : (radius > B ? B : radius);
-        const int Pg = (budget / B) < P ? (budget / B) : P;
+        int Pg = (budget / B) < P ? (budget / B) : P;
+        {   // small batches: more (smaller) projection groups, so that ~4 * NUM_CU workgroups exist
+            const int64_t wg_particles = (n + KDE_BLOCK - 1) / KDE_BLOCK;
+            const int64_t want_groups = (4 * NUM_CU + wg_particles - 1) / wg_particles;
+            if (want_groups > 1) {
+                int pg_small = (int)((P + want_groups - 1) / want_groups);
+                if (pg_small < 4) pg_small = P < 4 ? P : 4;
+                if (pg_small < Pg) Pg = pg_small;
+            }
+        }
         const int ngroups = (P + Pg - 1) / Pg;
         const int ds = d | 1;
         const size_t smem = sizeof(u64) * (size_t)Pg * B + sizeof(float) * ((size_t)Pg * ds + B);
@@ -674,11 +692,14 @@ extern "C" int mf_proj_kde1d_bwd(const float* x, int64_t n, int d, const float* 
     const int R = radius < 0 ? 0 : (radius > B ? B : radius);
     const int Pg = (KDE_LDS_FLOATS / B) < P ? (KDE_LDS_FLOATS / B) : P;
     const size_t smem = sizeof(float) * ((size_t)Pg * B + (size_t)Pg * d + B);
-    const int64_t G = (n + KDE_BLOCK - 1) / KDE_BLOCK;
+    // lanes per particle: enough workgroups to give every SIMD a wave (>= 1024 workgroups of 4 waves), at most 8
+    int CH = 1;
+    while (CH < 8 && CH * 2 <= P && (n * CH + KDE_BLOCK - 1) / KDE_BLOCK < 4 * NUM_CU) CH *= 2;
+    const int64_t G = (n * CH + KDE_BLOCK - 1) / KDE_BLOCK;
     ProfScope prof(PK_KDE1D_BWD, stream);
     MF_ALLOW_DYN_SMEM(proj_kde1d_bwd_kernel, smem);
     MF_LAUNCH(proj_kde1d_bwd_kernel, dim3((unsigned)G), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
-              1.0f / sigma, R, gS, gx, accumulate);
+              1.0f / sigma, R, gS, gx, accumulate, CH);
     return check_launch("mf_proj_kde1d_bwd");
 }
 
