@@ -573,6 +573,143 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_bwd_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Hand-scheduled MFMA groups for the one-wave-per-SIMD fused kernel.  The compiler's code for `linear64s` is
+// ds_read2 -> s_waitcnt lgkmcnt(0) -> 2 MFMAs -> ds_read2 -> ... with one reused register pair: harmless when a second
+// wave fills the LDS round trips, ~45 % MFMA efficiency when the wave is alone on its SIMD.  These blocks request the
+// weight fragments of group g + 1, issue the four (dependent) MFMAs of group g, and only then wait for LDS — by which
+// time the data has long arrived.  `KS` = distance in floats between consecutive k of one row/column in LDS
+// (1: row-major [out][in];  WS: column access).  All LDS offsets are immediates.
+#if !defined(MF_EMU)
+#define MF_ASM_CHAIN 1
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(size_t)p; }
+
+// group g: request the fragments of the group starting at k-step S4N into n[] (unconditionally: a skipped group's
+// fragments are never used), multiply-accumulate the four k-steps held in a[]
+template <int KS, int S4N>
+__device__ __forceinline__ void mfma4_pf(f32x16_t& acc, const float (&a)[4], float (&n)[4], unsigned addr, float b0, float b1,
+                                         float b2, float b3) {
+    asm volatile(
+        "ds_read_b32 %1, %9 offset:%14\n\t"
+        "ds_read_b32 %2, %9 offset:%15\n\t"
+        "ds_read_b32 %3, %9 offset:%16\n\t"
+        "ds_read_b32 %4, %9 offset:%17\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %5, %10, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %6, %11, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %7, %12, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %8, %13, %0\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "+v"(acc), "=&v"(n[0]), "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(addr), "v"(b0), "v"(b1), "v"(b2), "v"(b3),
+          "n"(kcol(S4N) * KS * 4), "n"(kcol(S4N + 1) * KS * 4), "n"(kcol(S4N + 2) * KS * 4), "n"(kcol(S4N + 3) * KS * 4));
+}
+// last group of a chain: no prefetch
+__device__ __forceinline__ void mfma4_last(f32x16_t& acc, const float (&a)[4], float b0, float b1, float b2, float b3) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
+        : "+v"(acc)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+// the compiler cannot see the MFMAs inside the blocks: pad the MFMA -> VALU read distance (18 wait states) by hand
+__device__ __forceinline__ void mfma_drain(f32x16_t& acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
+
+#endif
+
+// B operand accessors of a chain: k-step S of an accumulator pair, or of a 32-slot vector
+struct BTile {
+    const f32x16_t (&t)[2];
+    template <int S>
+    __device__ __forceinline__ float get() const { return t[S >> 4][S & 15]; }
+};
+struct BVec {
+    const float (&v)[32];
+    template <int S>
+    __device__ __forceinline__ float get() const { return v[S]; }
+};
+
+// acc += sum over the k-step groups [g0, g1) (four k-steps each) of A * B;  A fragment of k-step s = wl[kcol(s) * KS]
+// (wl: this lane's LDS row/column, KS = 1 for contiguous k, WS for a column walk), B(s) = b.get<s>().
+// gfx950: hand-scheduled blocks, fragment registers ping-pong between a0[] and a1[];  emulator: the plain loop.
+template <int KS, class BOp>
+__device__ __forceinline__ void chain64(f32x16_t& acc, const float* wl, int g0, int g1, const BOp& b) {
+#ifdef MF_ASM_CHAIN
+    const unsigned addr = lds_addr(wl);
+    float a0[4], a1[4];
+#define MF_GRP(G, CUR, NXT)                                                                                           \
+    if (G == g0 && G < g1) {                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) CUR[j] = wl[kcol(4 * G + j) * KS];                              \
+    }                                                                                                                 \
+    if (G >= g0 && G < g1)                                                                                            \
+        mfma4_pf<KS, (4 * G + 4) & 31>(acc, CUR, NXT, addr, b.template get<4 * G>(), b.template get<4 * G + 1>(),     \
+                                       b.template get<4 * G + 2>(), b.template get<4 * G + 3>());
+    MF_GRP(0, a0, a1) MF_GRP(1, a1, a0) MF_GRP(2, a0, a1) MF_GRP(3, a1, a0) MF_GRP(4, a0, a1) MF_GRP(5, a1, a0) MF_GRP(6, a0, a1)
+#undef MF_GRP
+    if (7 == g0 && 7 < g1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a1[j] = wl[kcol(28 + j) * KS];
+    }
+    if (7 >= g0 && 7 < g1)
+        mfma4_last(acc, a1, b.template get<28>(), b.template get<29>(), b.template get<30>(), b.template get<31>());
+    mfma_drain(acc);
+#else
+#define MF_STEP(S) if ((S) >= 4 * g0 && (S) < 4 * g1) acc = mfma(wl[kcol(S) * KS], b.template get<S>(), acc);
+#define MF_STEP4(S) MF_STEP(S) MF_STEP(S + 1) MF_STEP(S + 2) MF_STEP(S + 3)
+    MF_STEP4(0) MF_STEP4(4) MF_STEP4(8) MF_STEP4(12) MF_STEP4(16) MF_STEP4(20) MF_STEP4(24) MF_STEP4(28)
+#undef MF_STEP4
+#undef MF_STEP
+#endif
+}
+
+// input layer as ONE group of four k-steps (features 2s + hh): columns >= d multiply xb = 0 (the image words read there
+// are other, finite, weights), so no bounds are needed
+__device__ __forceinline__ void input_layer4(const float* W0, const float* b0, int S0, const float (&xb)[4], f32x16_t (&h)[2],
+                                             int col, int hh) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x16_t acc = bias_tile(b0, rt, hh);
+        const float* wrow = W0 + (32 * rt + col) * S0 + hh;
+#ifdef MF_ASM_CHAIN
+        float a[4];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) a[s_] = wrow[2 * s_];
+        mfma4_last(acc, a, xb[0], xb[1], xb[2], xb[3]);
+        mfma_drain(acc);
+#else
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) acc = mfma(wrow[2 * s_], xb[s_], acc);
+#endif
+        h[rt] = acc;
+    }
+    relu2(h);
+}
+
+// acc += sum over the k-step groups [0, g1) of A * B, g1 wave-uniform at run time, with ONE branch: a switch over g1
+// whose cases are separate straight-line chains with compile-time bounds.  (The eight per-group branches of
+// chain64(…, 0, g1, …) cost a lone wave ~40 % here; a single fall-through switch entered at group g1 - 1 made the
+// compiler copy the accumulator and the fragments at every label.)
+template <int KS, class BOp>
+__device__ __forceinline__ void chain64_upto(f32x16_t& acc, const float* wl, int g1, const BOp& b) {
+#ifdef MF_ASM_CHAIN
+    switch (g1) {
+        case 0: break;
+        case 1: chain64<KS>(acc, wl, 0, 1, b); break;
+        case 2: chain64<KS>(acc, wl, 0, 2, b); break;
+        case 3: chain64<KS>(acc, wl, 0, 3, b); break;
+        case 4: chain64<KS>(acc, wl, 0, 4, b); break;
+        case 5: chain64<KS>(acc, wl, 0, 5, b); break;
+        case 6: chain64<KS>(acc, wl, 0, 6, b); break;
+        case 7: chain64<KS>(acc, wl, 0, 7, b); break;
+        default: chain64<KS>(acc, wl, 0, 8, b); break;
+    }
+#else
+    chain64<KS>(acc, wl, 0, g1, b);
+#endif
+}
+
 // Diagnostic build only (-DMF_WS_DIAG): cycle stamps of pair 0 of every workgroup, read back with mf_debug_ws_read.
 #if defined(MF_WS_DIAG) && !defined(MF_EMU)
 __device__ unsigned long long g_ws_diag[NUM_CU * 16];
@@ -597,37 +734,45 @@ __device__ unsigned long long g_ws_diag[NUM_CU * 16];
 // so every wave keeps ONE accumulator block per stage (d last-layer blocks + L trunk levels: 9 x 16 registers for
 // d = 6, L = 3) for the whole kernel and adds it to gimage with float atomics at the end, exactly like
 // outer_accum_kernel.  Bias gradients are the row sums of S_A, accumulated by the waves of column tile 0.
-// Staged element (row, particle p) lives at row*32 + (((p >> 2) ^ row) & 7) * 4 + (p & 3): the 16-byte chunks of a
-// row are XOR-swizzled by the row so that both the producers' scalar writes (32 particles of one row) and the
-// consumers' 16-byte reads (4 particles of one row per lane, 8 rows per 128 bytes) are bank-conflict free without
-// padding.  LDS: trunk + COMPACT last-layer blocks (92 KB for d = 6) + 64 KB staging; d = 7 does not fit and uses the
-// two-kernel path.
+// Staged element (row, particle p) lives at row*32 + (((p >> 2) ^ (row >> 1)) & 7) * 4 + (p & 3): the 16-byte chunks
+// of a row are XOR-swizzled by row/2 so that both the producers' scalar writes (32 particles of one row, 32 banks) and the
+// consumers' ds_read_b128 (4 particles of one row per lane; 64 banks, 16-lane groups {0-3,12-15,20-27}, ...: the eight
+// even and the eight odd rows of a group must land on eight different 16-byte slots) are bank-conflict free without
+// padding.  LDS: trunk + COMPACT (and transposed) last-layer blocks (91 KB for d = 6) + 64 KB staging; d = 7 does not
+// fit and uses the two-kernel path.  With one wave per SIMD nothing hides an LDS or HBM round trip, so the MFMA chains
+// are hand-scheduled (chain64) and the particle rows of the next group are prefetched.
 constexpr int FB_BLOCK = 256;
 constexpr int FB_DMAX = 6;
 constexpr int FB_TILE = 2048;
 
-__device__ __forceinline__ int fb_blk_stride(const Sparsity& sp, int i) { return (2 * ((sp.kend3[i] + 3) & ~3)) | 1; }
+// hidden columns block i keeps (its k-steps rounded up to groups of four, two columns per k-step)
+__device__ __forceinline__ int fb_blk_cols(const Sparsity& sp, int i) { return 2 * ((sp.kend3[i] + 3) & ~3); }
 
-// this lane's four swizzled chunk offsets: accumulator register r of lane (col, hh) is MFMA row (r&3) + 8(r>>2) + 4hh,
-// so (row & 7) = (r & 3) + 4 hh
+// this lane's swizzled offsets: accumulator register r of lane (col, hh) is MFMA row (r&3) + 8(r>>2) + 4hh of its
+// 32-row tile, so ((row >> 1) & 7) = (4 ((r>>2) & 1) + (((r&3) + 4hh) >> 1)) & 7: eight variants, off[(r>>2)&1][r&3]
 struct StageLane {
-    int off[4];
+    int off[2][4];
 };
 __device__ __forceinline__ StageLane stage_lane(int col, int hh) {
     StageLane s;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s.off[j] = (((col >> 2) ^ (j + 4 * hh)) & 7) * 4 + (col & 3) + 32 * (j + 4 * hh);
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sw = (4 * e + ((j + 4 * hh) >> 1)) & 7;
+            s.off[e][j] = (((col >> 2) ^ sw) & 7) * 4 + (col & 3) + 32 * (j + 4 * hh);
+        }
     return s;
 }
 __device__ __forceinline__ void stage_tile(float* S, const StageLane& sl, const f32x16_t (&a)[2]) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[(32 * rt + 8 * (r >> 2)) * 32 + sl.off[r & 3]] = a[rt][r];
+        for (int r = 0; r < 16; ++r) S[(32 * rt + 8 * (r >> 2)) * 32 + sl.off[(r >> 2) & 1][r & 3]] = a[rt][r];
 }
 __device__ __forceinline__ void stage_tile(float* S, const StageLane& sl, const float (&v)[32]) {
 #pragma unroll
-    for (int m = 0; m < 32; ++m) S[(32 * (m >> 4) + 8 * ((m & 15) >> 2)) * 32 + sl.off[m & 3]] = v[m];
+    for (int m = 0; m < 32; ++m) S[(32 * (m >> 4) + 8 * ((m & 15) >> 2)) * 32 + sl.off[((m & 15) >> 2) & 1][m & 3]] = v[m];
 }
 
 struct DwFrag {
@@ -641,6 +786,9 @@ __device__ __forceinline__ void dw_load(DwFrag& f, const float* pa, const float*
     }
 }
 __device__ __forceinline__ void dw_mac(const DwFrag& f, bool mm, bool bias, f32x16_t& acc, float& bsum) {
+#ifdef MF_EXP_NOBIAS
+    bias = false;
+#endif
     if (bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) bsum += (f.a[q].x + f.a[q].y) + (f.a[q].z + f.a[q].w);
@@ -659,7 +807,7 @@ __device__ __forceinline__ void dw_mac(const DwFrag& f, bool mm, bool bias, f32x
 // sums of A.  Two fragment sets ping-pong so that the reads of the next tile are in flight during the MFMAs of this one.
 __device__ __forceinline__ void dw_accum(const float* SA, const float* SB, int ra, int rb, int t0, int npair, bool mm, bool bias,
                                          int lane, f32x16_t& acc, float& bsum) {
-    const int i = lane & 31, kk = lane >> 5, sw = i & 7;
+    const int i = lane & 31, kk = lane >> 5, sw = (i >> 1) & 7;
     const float* pa = SA + (32 * ra + i) * 32 + t0 * FB_TILE;
     const float* pb = SB + (32 * rb + i) * 32 + t0 * FB_TILE;
     int co[4];
@@ -700,22 +848,25 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                                                                         Sparsity sp) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
-    // ---- stage the image: trunk as is, last-layer blocks compacted to their non-zero columns
+    // ---- stage the image: trunk as is; last-layer block i TRANSPOSED and compacted to the hidden columns its mask
+    // leaves non-zero: T_i[c][m] = W3_i[m][c], c < ncols_i, row stride WS.  Both products then walk LDS with immediate
+    // offsets: phi = W3 h reads column m of T (stride WS), gh += W3^T gphi reads row c of T (contiguous).
     for (int i = threadIdx.x * 4; i < g.offW3; i += FB_BLOCK * 4)
         *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(image + i);
     int off = g.offW3;
     for (int i = 0; i < d; ++i) {
-        const int st = fb_blk_stride(sp, i);
-        const int nc = st - 1;
+        const int nc = fb_blk_cols(sp, i);
         for (int e = threadIdx.x; e < HID * nc; e += FB_BLOCK) {
-            const int r = e / nc, c = e - r * nc;
-            lds[off + r * st + c] = image[g.offW3 + (i * HID + r) * WS + c];
+            const int c = e >> 6, r = e & 63;
+            lds[off + c * WS + r] = image[g.offW3 + (i * HID + r) * WS + c];
         }
-        off += HID * st;
+        off += nc * WS;
     }
     const int offB3c = off;
     for (int e = threadIdx.x; e < d * HID; e += FB_BLOCK) lds[offB3c + e] = image[g.offB3 + e];
-    float* SA = lds + ((offB3c + d * HID + 3) & ~3);
+    float* zrow = lds + offB3c + d * HID;                  // 64 zeros: the "row" of a hidden column a block does not store
+    if (threadIdx.x < HID) zrow[threadIdx.x] = 0.0f;
+    float* SA = lds + ((offB3c + d * HID + HID + 3) & ~3);
     float* SB = SA + 4 * FB_TILE;
     __syncthreads();
 
@@ -742,29 +893,59 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         for (int r = 0; r < 16; ++r) accT[l][r] = 0.0f;
     }
 
-    unsigned long long c_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0_, tl_;
+    unsigned long long c_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0_, tl_, t1_;
     const int64_t ntiles = (n + 31) / 32;
     const int64_t ngroups = (ntiles + 3) / 4;
+    // the particle rows (x, dL/dy, dL/dlog_prob) of the NEXT group are requested at the top of the current one: a lone
+    // wave per SIMD would otherwise sit through every HBM round trip
+    float xn[FB_DMAX], gyn[FB_DMAX], gln;
+    auto load_rows = [&](int64_t grp2, float (&xo)[FB_DMAX], float (&go)[FB_DMAX], float& glo) {
+        const int64_t p2 = (grp2 * 4 + wid) * 32 + col;
+        const bool v2 = p2 < n;
+        const int64_t pc2 = v2 ? p2 : n - 1;
+#pragma unroll
+        for (int j = 0; j < FB_DMAX; ++j) {
+            xo[j] = (j < d) ? x[pc2 * d + j] : 0.0f;
+            go[j] = (v2 && j < d) ? gy[pc2 * d + j] : 0.0f;
+        }
+        glo = v2 ? -glogp[pc2] : 0.0f;
+    };
+    load_rows(blockIdx.x, xn, gyn, gln);
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         MF_NO_HOIST();
         tl_ = t0_ = WS_T();
         const int64_t tile = grp * 4 + wid;
         const int64_t p = tile * 32 + col;
         const bool valid = p < n;
-        const int64_t pc = valid ? p : n - 1;
-        const float* xp = x + pc * d;
+        float xr[FB_DMAX], gyr[FB_DMAX];
+#pragma unroll
+        for (int j = 0; j < FB_DMAX; ++j) {
+            xr[j] = xn[j];
+            gyr[j] = gyn[j];
+        }
+        const float gl = gln;
+        {
+            const int64_t gnext = grp + gridDim.x;
+            load_rows(gnext < ngroups ? gnext : grp, xn, gyn, gln);
+        }
         float xb[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) xb[s] = (2 * s + hh < d) ? xp[2 * s + hh] : 0.0f;
+        for (int s = 0; s < 4; ++s) xb[s] = (2 * s < FB_DMAX) ? (hh ? (2 * s + 1 < FB_DMAX ? xr[2 * s + 1] : 0.0f) : xr[2 * s]) : 0.0f;
         // ---- recompute the trunk; h[0] is not kept (it is 8 MFMAs to recompute, and 32 registers to keep)
         f32x16_t h[L][2];
         {
             f32x16_t h0[2];
-            input_layer(lds + g.offW0, lds + g.offB0, g.S0, d, xb, h0, col, hh);
+            input_layer4(lds + g.offW0, lds + g.offB0, g.S0, xb, h0, col, hh);
 #pragma unroll
             for (int l = 1; l < L; ++l) {
                 const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
-                linear64(W, W + HID * WS, l == 1 ? h0 : h[l - 1], h[l], col, hh, sp.kend_h[0], sp.kend_h[1]);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    h[l][rt] = bias_tile(W + HID * WS, rt, hh);
+                    // trunk chains run DENSE here: 8 straight-line groups (64 MFMAs) beat the 5 + 8 mask-bounded groups
+                    // (52 MFMAs) whose wave-uniform branches break the ds_read / MFMA pipelining of a lone wave
+                    chain64<1>(h[l][rt], W + (32 * rt + col) * WS + 4 * hh, 0, 8, BTile{l == 1 ? h0 : h[l - 1]});
+                }
                 relu2(h[l]);
             }
             if (L == 1) { h[0][0] = h0[0]; h[0][1] = h0[1]; }
@@ -781,26 +962,34 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             gh[1][r] = 0.0f;
             gacc[r] = 0.0f;
         }
-        const float gl = valid ? -glogp[pc] : 0.0f;
         int w3off = g.offW3;
 #pragma unroll 1
         for (int i = 0; i < d; ++i) {
             float v[32], gv[32];
-            const int st = fb_blk_stride(sp, i);
-            const float* W3 = lds + w3off;
-            w3off += HID * st;
+            const int nc = fb_blk_cols(sp, i);
+            const float* W3 = lds + w3off;                 // T_i[c][m]
+            w3off += nc * WS;
             t0_ = WS_T();
             {
                 f32x16_t phi[2];
-                linear64s(W3, st, lds + offB3c + i * HID, h[L - 1], phi, col, hh, sp.kend3[i], sp.kend3[i]);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    phi[rt] = bias_tile(lds + offB3c + i * HID, rt, hh);
+                    chain64_upto<WS>(phi[rt], W3 + 4 * hh * WS + 32 * rt + col, (sp.kend3[i] + 3) >> 2, BTile{h[L - 1]});
+                }
 #pragma unroll
                 for (int m = 0; m < 32; ++m) v[m] = phi[m >> 4][m & 15];
             }
             WS_ACC(c_[1], t0_);
             t0_ = WS_T();
-            const float gyi = valid ? gy[pc * d + i] : 0.0f;
+            float xi = xr[0], gyi = gyr[0];
+#pragma unroll
+            for (int j = 1; j < FB_DMAX; ++j) {
+                xi = (i == j) ? xr[j] : xi;
+                gyi = (i == j) ? gyr[j] : gyi;
+            }
             float yi, li, gxd;
-            rqs_apply<K, 1>(v, xp[i], hh, yi, li, gyi, gl, gv, gxd);
+            rqs_apply<K, 1>(v, xi, hh, yi, li, gyi, gl, gv, gxd);
             WS_ACC(c_[2], t0_);
 #pragma unroll
             for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
@@ -824,6 +1013,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 dw_accum(SA, SB, ra, rb, t0, t1, mm, bias, lane, accO[0], bsO[0]);
                 WS_ACC(c_[6], t0_);
                 t0_ = WS_T();
+#ifndef MF_EXP_NOROT
                 {
                     const f32x16_t ta = accO[0];
                     const float tb = bsO[0];
@@ -835,10 +1025,17 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                     accO[FB_DMAX - 1] = ta;
                     bsO[FB_DMAX - 1] = tb;
                 }
+#endif
             }
             WS_ACC(c_[7], t0_);
             t0_ = WS_T();
-            linear64s_t(W3, st, gv, gh, col, hh, sp.kend3[i] > 0, sp.rt1[i] != 0);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                if (rt ? sp.rt1[i] != 0 : sp.kend3[i] > 0) {       // hidden tile rt receives something from block i
+                    const int c = 32 * rt + col;
+                    chain64<1>(gh[rt], (c < nc ? W3 + c * WS : zrow) + 4 * hh, 0, 8, BVec{gv});
+                }
+            }
             WS_ACC(c_[8], t0_);
         }
         t0_ = WS_T();
@@ -861,22 +1058,34 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gh[rt][r] = (h[l][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
-            if (l == 1) input_layer(lds + g.offW0, lds + g.offB0, g.S0, d, xb, h[0], col, hh);
+            t1_ = WS_T();
+            if (l == 1) input_layer4(lds + g.offW0, lds + g.offB0, g.S0, xb, h[0], col, hh);
             __syncthreads();                               // the previous product has read S_A / S_B
             stage_tile(myA, sl, gh);
             stage_tile(myB, sl, h[l - 1]);
             __syncthreads();
+            WS_ACC(c_[12], t1_);
+            t1_ = WS_T();
             dw_accum(SA, SB, fra, frb, 0, 2, !(fra == 0 && frb == 1 && sp.kend_h[0] <= 16), frb == 0, lane, accT[l], bsT[l]);
+            WS_ACC(c_[13], t1_);
+            t1_ = WS_T();
             f32x16_t t[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 t[0][r] = 0.0f;
                 t[1][r] = 0.0f;
             }
-            linear64_t(lds + g.offWh + (l - 1) * (HID * WS + HID), gh, t, col, hh, sp.kbeg_ht[0], sp.kbeg_ht[1]);
+            {
+                const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+                    chain64<WS>(t[rt], W + 4 * hh * WS + 32 * rt + col, 0, 8, BTile{gh});
+            }
             gh[0] = t[0];
             gh[1] = t[1];
+            WS_ACC(c_[14], t1_);
         }
+        t1_ = WS_T();
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -884,20 +1093,21 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         __syncthreads();
         stage_tile(myA, sl, gh);
         if (hh == 0) {                                     // S_B rows 0..d-1 <- x (rows >= d: stale finite values, never flushed)
-            for (int j = 0; j < d; ++j) myB[j * 32 + ((((col >> 2) ^ j) & 7) << 2) + (col & 3)] = valid ? xp[j] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < FB_DMAX; ++j)
+                if (j < d) myB[j * 32 + ((((col >> 2) ^ (j >> 1)) & 7) << 2) + (col & 3)] = xr[j];
         }
         __syncthreads();
         dw_accum(SA, SB, hra, 0, ht0, 1, true, true, lane, accT[0], bsT[0]);
+        WS_ACC(c_[15], t1_);
         WS_ACC(c_[9], t0_);
         t0_ = WS_T();
         if (gx != nullptr) {
+            // rows >= d of the result are never stored, so the lanes col >= d may multiply whatever W0 words they read
             const float* wcol = lds + g.offW0 + 4 * hh * g.S0 + col;
-#pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
-                const float a = (col < d) ? wcol[kk * g.S0] : 0.0f;
-                gacc = mfma(a, gh[s >> 4][s & 15], gacc);
-            }
+            if (g.S0 == 7) chain64<7>(gacc, wcol, 0, 8, BTile{gh});
+            else if (g.S0 == 5) chain64<5>(gacc, wcol, 0, 8, BTile{gh});
+            else chain64<3>(gacc, wcol, 0, 8, BTile{gh});
             if (valid) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -909,7 +1119,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
     }
 #if defined(MF_WS_DIAG) && !defined(MF_EMU)
     if (threadIdx.x == 0)
-        for (int q = 0; q < 12; ++q) g_ws_diag[blockIdx.x * 16 + q] = c_[q];
+        for (int q = 0; q < 16; ++q) g_ws_diag[blockIdx.x * 16 + q] = c_[q];
 #endif
     // ---- flush the accumulators (image coordinates)
 #pragma unroll
@@ -1712,16 +1922,18 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
         }
     }
     // fused backward + parameter gradients (no scratch traffic): needs the mask structure for the compact image.
-    // Opt-in (MENTFLOW_BWD_FUSED=1): measured 23.1 ms against 20.4 ms for the two-kernel path at 2 M particles (C4) and
-    // 4 % faster than it at 200 K — one wave per SIMD exposes every LDS round trip of the chain.
+    // Default (MENTFLOW_BWD_FUSED=0 selects the two-kernel path): 19.2 ms against 11.1 + 9.3 ms at 2 M particles (C4).
     {
         const char* e = getenv("MENTFLOW_BWD_FUSED");
-        const bool want_fused = (e && atoi(e) == 1) && !bwd_ws;
+        // small batches (<= 1024 tiles: at most one 4-tile group per workgroup) keep the two-kernel path, whose
+        // per-workgroup set-up (image staging, final flush of the accumulators) is lighter: 0.54 vs 0.66 ms at 25 000
+        const bool forced = e && atoi(e) == 1;
+        const bool want_fused = !(e && atoi(e) == 0) && !bwd_ws && (forced || (n + 31) / 32 > 4 * NUM_CU);
         if (want_fused && !launched && order != nullptr && d <= FB_DMAX) {
             const ImageLayout gl_ = image_layout(d, hidden_layers, d);
             size_t fl = gl_.offW3;
-            for (int i = 0; i < d; ++i) fl += (size_t)HID * ((2 * ((sp.kend3[i] + 3) & ~3)) | 1);
-            fl += (size_t)d * HID;
+            for (int i = 0; i < d; ++i) fl += (size_t)WS * (2 * ((sp.kend3[i] + 3) & ~3));
+            fl += (size_t)d * HID + HID;
             fl = (fl + 3) & ~(size_t)3;
             const size_t smem_f = sizeof(float) * (fl + 8 * (size_t)FB_TILE);
             if (smem_f <= 160 * 1024) {
