@@ -180,8 +180,11 @@ def main():
         # particles one launch of the dominant kernel processes (backward runs in chunks)
         launches_per_step = dom_cnt / args.steps
         per_launch_particles = per_gpu * (T if dom in ("flow_layer_fwd", "flow_layer_bwd", "outer_accum") else 1) / launches_per_step
-        alg_flops = {"flow_layer_fwd": lf, "flow_layer_bwd": lf, "outer_accum": lf}.get(dom)
-        roof = {"kernel": dom, "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_MFMA_F32, "traffic": None}
+        # the fused backward kernel (no outer_accum launches) does backward-data AND the parameter gradients: 2 F_layer
+        fused_bwd = "outer_accum" not in flow_kernels
+        alg_flops = {"flow_layer_fwd": lf, "flow_layer_bwd": 2 * lf if fused_bwd else lf, "outer_accum": lf}.get(dom)
+        roof = {"kernel": dom + (" (fused: backward-data + parameter gradients)" if dom == "flow_layer_bwd" and fused_bwd else ""),
+                "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_MFMA_F32, "traffic": None}
         if alg_flops is not None:
             roof["achieved"] = alg_flops * per_launch_particles / (dom_ms / dom_cnt * 1e-3) / 1e12
         else:   # a KDE kernel dominates: HBM-bound byte work, algorithmic bytes = particle rows read (+ written)

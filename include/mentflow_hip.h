@@ -57,10 +57,12 @@ int mf_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, i
  *       units sorted by dependency class as packing.py lays them out; NULL = dense products (any image).
  * bwd:  given gy[n,d] = dL/dy and glogp[n] = dL/dlogp, writes gx[n,d] = dL/dx (NULL for the first layer: the
  *       base draw needs no gradient) and accumulates dL/d(image) into gimage (same layout as image; must be
- *       zeroed by the caller before the first chunk).  `scratch` needs mf_flow_bwd_scratch_floats(n,...)
- *       floats.                                                                                             */
+ *       zeroed by the caller before the first chunk).  `scratch` needs mf_flow_bwd_scratch_floats(n,...,order)
+ *       floats: 0 when the call takes the fused kernel (parameter gradients inside the backward kernel: large
+ *       batches with `order`), else (2 hidden_layers + d) * 64 floats per particle for the hand-off to the
+ *       parameter-gradient kernel (callers then process the batch in chunks to bound it).                    */
 int64_t mf_flow_image_floats(int d, int hidden_layers);
-int64_t mf_flow_bwd_scratch_floats(int64_t n, int d, int hidden_layers);
+int64_t mf_flow_bwd_scratch_floats(int64_t n, int d, int hidden_layers, const int32_t* order);
 int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
                           const float* x, int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp,
                           void* stream);

@@ -30,7 +30,7 @@ PROTOTYPES = {
     "mf_prof_report": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mf_gather_f32": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _ptr]),
     "mf_flow_image_floats": (_i64, [_i32, _i32]),
-    "mf_flow_bwd_scratch_floats": (_i64, [_i64, _i32, _i32]),
+    "mf_flow_bwd_scratch_floats": (_i64, [_i64, _i32, _i32, _ptr]),
     "mf_flow_rqs_layer_fwd": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32, _ptr]),
     "mf_flow_rqs_layer_bwd": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
     "mf_flow_rqs_layer_inv": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr]),

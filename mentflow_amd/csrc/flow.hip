@@ -1848,7 +1848,29 @@ using namespace mf;
 
 extern "C" int64_t mf_flow_image_floats(int d, int hidden_layers) { return image_layout(d, hidden_layers, d).total; }
 
-extern "C" int64_t mf_flow_bwd_scratch_floats(int64_t n, int d, int hidden_layers) {
+// Does mf_flow_rqs_layer_bwd take the fused kernel (parameter gradients inside the backward kernel, no scratch) for
+// this call?  It needs the mask structure (order) for the compact last-layer image, d <= FB_DMAX accumulator blocks and
+// an LDS budget that fits; small batches (<= 1024 tiles: at most one 4-tile group per workgroup) keep the two-kernel
+// path, whose per-workgroup set-up is lighter (0.54 vs 0.66 ms at 25 000 particles).  MENTFLOW_BWD_FUSED=0 / 1
+// forces the choice where both are possible.
+static bool rqs_bwd_fused(int64_t n, int d, int hidden_layers, const int32_t* order, const Sparsity& sp, size_t* smem) {
+    const char* e = getenv("MENTFLOW_BWD_FUSED");
+    const char* w = getenv("MENTFLOW_BWD_WS");
+    if ((e && atoi(e) == 0) || (w && atoi(w) == 1) || order == nullptr || d > FB_DMAX) return false;
+    if (!(e && atoi(e) == 1) && (n + 31) / 32 <= 4 * NUM_CU) return false;
+    size_t fl = image_layout(d, hidden_layers, d).offW3;
+    for (int i = 0; i < d; ++i) fl += (size_t)WS * (2 * ((sp.kend3[i] + 3) & ~3));
+    fl += (size_t)d * HID + HID;
+    fl = (fl + 3) & ~(size_t)3;
+    *smem = sizeof(float) * (fl + 8 * (size_t)FB_TILE);
+    return *smem <= 160 * 1024;
+}
+
+extern "C" int64_t mf_flow_bwd_scratch_floats(int64_t n, int d, int hidden_layers, const int32_t* order) {
+    if (order != nullptr && d >= 1 && d <= FLOW_DMAX) {
+        size_t smem;
+        if (rqs_bwd_fused(n, d, hidden_layers, order, make_sparsity(d, order, d), &smem)) return 0;
+    }
     const int64_t npad = ((n + 31) / 32) * 32;
     return (2 * (int64_t)hidden_layers + d) * npad * 64;
 }
@@ -1892,7 +1914,7 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
     if (flow_check(d, hidden_layers, n)) return 1;
     if (n == 0) return 0;
     const Sparsity sp = make_sparsity(d, order, d);
-    if (scratch_floats < mf_flow_bwd_scratch_floats(n, d, hidden_layers)) return fail("scratch too small");
+    if (scratch_floats < mf_flow_bwd_scratch_floats(n, d, hidden_layers, order)) return fail("scratch too small");
     const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, d).total;
     bool launched = false;
     // wave-specialised variant (matrix waves + vector waves): needs the mask structure (order) for the compact image
@@ -1921,22 +1943,11 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
 #undef XW
         }
     }
-    // fused backward + parameter gradients (no scratch traffic): needs the mask structure for the compact image.
-    // Default (MENTFLOW_BWD_FUSED=0 selects the two-kernel path): 19.2 ms against 11.1 + 9.3 ms at 2 M particles (C4).
+    // fused backward + parameter gradients (no scratch traffic): 19.2 ms against 11.1 + 9.3 ms at 2 M particles (C4)
     {
-        const char* e = getenv("MENTFLOW_BWD_FUSED");
-        // small batches (<= 1024 tiles: at most one 4-tile group per workgroup) keep the two-kernel path, whose
-        // per-workgroup set-up (image staging, final flush of the accumulators) is lighter: 0.54 vs 0.66 ms at 25 000
-        const bool forced = e && atoi(e) == 1;
-        const bool want_fused = !(e && atoi(e) == 0) && !bwd_ws && (forced || (n + 31) / 32 > 4 * NUM_CU);
-        if (want_fused && !launched && order != nullptr && d <= FB_DMAX) {
-            const ImageLayout gl_ = image_layout(d, hidden_layers, d);
-            size_t fl = gl_.offW3;
-            for (int i = 0; i < d; ++i) fl += (size_t)WS * (2 * ((sp.kend3[i] + 3) & ~3));
-            fl += (size_t)d * HID + HID;
-            fl = (fl + 3) & ~(size_t)3;
-            const size_t smem_f = sizeof(float) * (fl + 8 * (size_t)FB_TILE);
-            if (smem_f <= 160 * 1024) {
+        size_t smem_f = 0;
+        if (!launched && rqs_bwd_fused(n, d, hidden_layers, order, sp, &smem_f)) {
+            {
                 const int64_t ngroups = ((n + 31) / 32 + 3) / 4;
                 const int gf = (int)(ngroups > NUM_CU ? NUM_CU : ngroups);
 #define XF(KK, LL)                                                                                                    \
@@ -1950,6 +1961,8 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
                 MF_RQS_CASES(XF)
 #undef XF
                 if (launched) return check_launch("mf_flow_rqs_layer_bwd(fused)");
+                return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: bins in {8,20}, hidden_layers in {2,3})",
+                            bins, hidden_layers);
             }
         }
     }

@@ -111,7 +111,15 @@ class FlowSampleFn(torch.autograd.Function):
         gimages = torch.zeros_like(images)
         chunk = min(n, spec.bwd_chunk)
         if spec.kind == "rqs":
-            scratch_floats = _lib.get_lib().mf_flow_bwd_scratch_floats(chunk, spec.d, spec.L)
+            lib = _lib.get_lib()
+            orders = spec.orders if spec.sparse else [None]
+
+            def need(m):
+                return max(lib.mf_flow_bwd_scratch_floats(m, spec.d, spec.L, o) for o in orders)
+
+            if need(n) == 0:
+                chunk = n                       # fused backward: no hand-off scratch, one launch per layer
+            scratch_floats = need(chunk)
         else:
             scratch_floats = _lib.get_lib().mf_flow_affine_bwd_scratch_floats(chunk, spec.L)
         scratch = torch.empty(max(scratch_floats, 1), dtype=_F32, device=dev)

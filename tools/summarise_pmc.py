@@ -17,7 +17,8 @@ src = os.path.join(root, "gpurun_out", f"profiles_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-KEY = {"rqs_layer_fwd_kernel": "flow_layer_fwd", "rqs_layer_bwd_kernel": "flow_layer_bwd", "outer_accum_kernel": "outer_accum",
+KEY = {"rqs_layer_fwd_kernel": "flow_layer_fwd", "rqs_layer_bwd_kernel": "flow_layer_bwd",
+       "rqs_layer_bwd_fused_kernel": "flow_layer_bwd", "outer_accum_kernel": "outer_accum",
        "proj_kde1d_fwd_kernel": "kde1d_fwd", "proj_kde1d_bwd_kernel": "kde1d_bwd", "proj_kde2d_fwd_kernel": "kde2d_fwd",
        "proj_kde2d_bwd_kernel": "kde2d_bwd"}
 
