@@ -1107,7 +1107,8 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             const float* wcol = lds + g.offW0 + 4 * hh * g.S0 + col;
             if (g.S0 == 7) chain64<7>(gacc, wcol, 0, 8, BTile{gh});
             else if (g.S0 == 5) chain64<5>(gacc, wcol, 0, 8, BTile{gh});
-            else chain64<3>(gacc, wcol, 0, 8, BTile{gh});
+            else if (g.S0 == 3) chain64<3>(gacc, wcol, 0, 8, BTile{gh});
+            else chain64<1>(gacc, wcol, 0, 8, BTile{gh});
             if (valid) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
