@@ -963,8 +963,8 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             gacc[r] = 0.0f;
         }
         int w3off = g.offW3;
-#pragma unroll 1
-        for (int i = 0; i < d; ++i) {
+        // one feature: phi_i, spline forward + adjoint, stage gphi_i, this wave's share of dW3_i, gh += W3_i^T gphi_i
+        auto feature = [&](int i, f32x16_t& accF, float& bsF) {
             float v[32], gv[32];
             const int nc = fb_blk_cols(sp, i);
             const float* W3 = lds + w3off;                 // T_i[c][m]
@@ -1008,24 +1008,9 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 const int ra = full ? fra : hra, rb = full ? frb : 0;
                 const int t0 = full ? 0 : ht0, t1 = full ? 2 : 1;
                 const bool mm = sp.kend3[i] > 0, bias = rb == 0;
-                // the accumulator of the current feature is always accO[0]: the array is rotated by one after every
-                // feature (register moves) instead of being indexed by the runtime feature number
-                dw_accum(SA, SB, ra, rb, t0, t1, mm, bias, lane, accO[0], bsO[0]);
+                dw_accum(SA, SB, ra, rb, t0, t1, mm, bias, lane, accF, bsF);
                 WS_ACC(c_[6], t0_);
                 t0_ = WS_T();
-#ifndef MF_EXP_NOROT
-                {
-                    const f32x16_t ta = accO[0];
-                    const float tb = bsO[0];
-#pragma unroll
-                    for (int k = 0; k + 1 < FB_DMAX; ++k) {
-                        accO[k] = accO[k + 1];
-                        bsO[k] = bsO[k + 1];
-                    }
-                    accO[FB_DMAX - 1] = ta;
-                    bsO[FB_DMAX - 1] = tb;
-                }
-#endif
             }
             WS_ACC(c_[7], t0_);
             t0_ = WS_T();
@@ -1037,20 +1022,31 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 }
             }
             WS_ACC(c_[8], t0_);
+        };
+        // The feature loop stays rolled (the spline is ~8 KB of code), so the accumulator of "the current feature"
+        // cannot be indexed by i: two features per iteration use accO[0] and accO[1], then the array is rotated by two
+        // (register moves; FB_DMAX / 2 iterations bring every block back to its place).  A switch on i made the
+        // register allocator copy all six blocks at every merge; rotating after every feature cost twice the moves.
+        static_assert(FB_DMAX % 2 == 0, "two features per iteration");
+#pragma unroll 1
+        for (int i = 0; i < FB_DMAX; i += 2) {
+            if (i < d) feature(i, accO[0], bsO[0]);
+            if (i + 1 < d) feature(i + 1, accO[1], bsO[1]);
+#ifndef MF_EXP_NOROT
+            const f32x16_t ta0 = accO[0], ta1 = accO[1];
+            const float tb0 = bsO[0], tb1 = bsO[1];
+#pragma unroll
+            for (int k = 0; k + 2 < FB_DMAX; ++k) {
+                accO[k] = accO[k + 2];
+                bsO[k] = bsO[k + 2];
+            }
+            accO[FB_DMAX - 2] = ta0;
+            accO[FB_DMAX - 1] = ta1;
+            bsO[FB_DMAX - 2] = tb0;
+            bsO[FB_DMAX - 1] = tb1;
+#endif
         }
         t0_ = WS_T();
-#pragma unroll 1
-        for (int e = d; e < FB_DMAX; ++e) {                // d < FB_DMAX: finish the turn so that feature i is accO[i] again
-            const f32x16_t ta = accO[0];
-            const float tb = bsO[0];
-#pragma unroll
-            for (int k = 0; k + 1 < FB_DMAX; ++k) {
-                accO[k] = accO[k + 1];
-                bsO[k] = bsO[k + 1];
-            }
-            accO[FB_DMAX - 1] = ta;
-            bsO[FB_DMAX - 1] = tb;
-        }
         // ---- trunk backward
 #pragma unroll
         for (int l = L - 1; l >= 1; --l) {
