@@ -786,9 +786,6 @@ __device__ __forceinline__ void dw_load(DwFrag& f, const float* pa, const float*
     }
 }
 __device__ __forceinline__ void dw_mac(const DwFrag& f, bool mm, bool bias, f32x16_t& acc, float& bsum) {
-#ifdef MF_EXP_NOBIAS
-    bias = false;
-#endif
     if (bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) bsum += (f.a[q].x + f.a[q].y) + (f.a[q].z + f.a[q].w);
@@ -1032,7 +1029,6 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         for (int i = 0; i < FB_DMAX; i += 2) {
             if (i < d) feature(i, accO[0], bsO[0]);
             if (i + 1 < d) feature(i + 1, accO[1], bsO[1]);
-#ifndef MF_EXP_NOROT
             const f32x16_t ta0 = accO[0], ta1 = accO[1];
             const float tb0 = bsO[0], tb1 = bsO[1];
 #pragma unroll
@@ -1044,7 +1040,6 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             accO[FB_DMAX - 1] = ta1;
             bsO[FB_DMAX - 2] = tb0;
             bsO[FB_DMAX - 1] = tb1;
-#endif
         }
         t0_ = WS_T();
         // ---- trunk backward
