@@ -733,7 +733,7 @@ __device__ unsigned long long g_ws_diag[NUM_CU * 16];
 //     stage with one column tile        : wave w owns block (w & 1, 0) for tiles 2 (w >> 1) .. + 1  (k split)
 // so every wave keeps ONE accumulator block per stage (d last-layer blocks + L trunk levels: 9 x 16 registers for
 // d = 6, L = 3) for the whole kernel and adds it to gimage with float atomics at the end, exactly like
-// outer_accum_kernel.  Bias gradients are the row sums of S_A, accumulated by the waves of column tile 0.
+// outer_accum_kernel.  Bias gradients are the row sums of S_A; the waves that share a row tile split the tiles.
 // Staged element (row, particle p) lives at row*32 + (((p >> 2) ^ (row >> 1)) & 7) * 4 + (p & 3): the 16-byte chunks
 // of a row are XOR-swizzled by row/2 so that both the producers' scalar writes (32 particles of one row, 32 banks) and the
 // consumers' ds_read_b128 (4 particles of one row per lane; 64 banks, 16-lane groups {0-3,12-15,20-27}, ...: the eight
@@ -801,9 +801,11 @@ __device__ __forceinline__ void dw_mac(const DwFrag& f, bool mm, bool bias, f32x
     }
 }
 // acc += A[rows 32 ra ..][particles] * B[rows 32 rb ..][particles]^T over the staged tiles [t0, t0 + 2 npair);  bsum += row
-// sums of A.  Two fragment sets ping-pong so that the reads of the next tile are in flight during the MFMAs of this one.
-__device__ __forceinline__ void dw_accum(const float* SA, const float* SB, int ra, int rb, int t0, int npair, bool mm, bool bias,
-                                         int lane, f32x16_t& acc, float& bsum) {
+// sums of A over the tile pairs selected by bias_pair (-1: every pair; p: pair p only — the two waves that share a row
+// tile of a full product split its bias sums between them).  Two fragment sets ping-pong so that the reads of the next
+// tile are in flight during the MFMAs of this one.
+__device__ __forceinline__ void dw_accum(const float* SA, const float* SB, int ra, int rb, int t0, int npair, bool mm,
+                                         int bias_pair, int lane, f32x16_t& acc, float& bsum) {
     const int i = lane & 31, kk = lane >> 5, sw = (i >> 1) & 7;
     const float* pa = SA + (32 * ra + i) * 32 + t0 * FB_TILE;
     const float* pb = SB + (32 * rb + i) * 32 + t0 * FB_TILE;
@@ -814,6 +816,7 @@ __device__ __forceinline__ void dw_accum(const float* SA, const float* SB, int r
     dw_load(f0, pa, pb, co);
 #pragma unroll 1
     for (int u = 0; u < npair; ++u) {
+        const bool bias = bias_pair < 0 || bias_pair == u;
         dw_load(f1, pa + FB_TILE, pb + FB_TILE, co);
         dw_mac(f0, mm, bias, acc, bsum);
         if (u + 1 < npair) dw_load(f0, pa + 2 * FB_TILE, pb + 2 * FB_TILE, co);
@@ -1004,8 +1007,8 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 const bool full = sp.rt1[i] != 0;
                 const int ra = full ? fra : hra, rb = full ? frb : 0;
                 const int t0 = full ? 0 : ht0, t1 = full ? 2 : 1;
-                const bool mm = sp.kend3[i] > 0, bias = rb == 0;
-                dw_accum(SA, SB, ra, rb, t0, t1, mm, bias, lane, accF, bsF);
+                const bool mm = sp.kend3[i] > 0;
+                dw_accum(SA, SB, ra, rb, t0, t1, mm, full ? frb : -1, lane, accF, bsF);
                 WS_ACC(c_[6], t0_);
                 t0_ = WS_T();
             }
@@ -1057,7 +1060,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             __syncthreads();
             WS_ACC(c_[12], t1_);
             t1_ = WS_T();
-            dw_accum(SA, SB, fra, frb, 0, 2, !(fra == 0 && frb == 1 && sp.kend_h[0] <= 16), frb == 0, lane, accT[l], bsT[l]);
+            dw_accum(SA, SB, fra, frb, 0, 2, !(fra == 0 && frb == 1 && sp.kend_h[0] <= 16), frb, lane, accT[l], bsT[l]);
             WS_ACC(c_[13], t1_);
             t1_ = WS_T();
             f32x16_t t[2];
@@ -1089,7 +1092,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 if (j < d) myB[j * 32 + ((((col >> 2) ^ (j >> 1)) & 7) << 2) + (col & 3)] = xr[j];
         }
         __syncthreads();
-        dw_accum(SA, SB, hra, 0, ht0, 1, true, true, lane, accT[0], bsT[0]);
+        dw_accum(SA, SB, hra, 0, ht0, 1, true, -1, lane, accT[0], bsT[0]);
         WS_ACC(c_[15], t1_);
         WS_ACC(c_[9], t0_);
         t0_ = WS_T();
@@ -1120,14 +1123,14 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             const bool full = sp.rt1[i] != 0;
             const int ra = full ? fra : hra, rb = full ? frb : 0;
             if (sp.kend3[i] > 0) dw_flush(gimage + g.offW3 + i * HID * WS, WS, HID, ra, rb, lane, accO[i]);
-            if (rb == 0) bias_flush(gimage + g.offB3 + i * HID, ra, lane, bsO[i]);
+            bias_flush(gimage + g.offB3 + i * HID, ra, lane, bsO[i]);
         }
     }
 #pragma unroll
     for (int l = 1; l < L; ++l) {
         float* gW = gimage + g.offWh + (l - 1) * (HID * WS + HID);
         if (!(fra == 0 && frb == 1 && sp.kend_h[0] <= 16)) dw_flush(gW, WS, HID, fra, frb, lane, accT[l]);
-        if (frb == 0) bias_flush(gW + HID * WS, fra, lane, bsT[l]);
+        bias_flush(gW + HID * WS, fra, lane, bsT[l]);
     }
     dw_flush(gimage + g.offW0, g.S0, d, hra, 0, lane, accT[0]);
     bias_flush(gimage + g.offB0, hra, lane, bsT[0]);
