@@ -1136,304 +1136,6 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
     bias_flush(gimage + g.offB0, hra, lane, bsT[0]);
 }
 
-// =========================================================================================== backward, RQS, wave-specialised
-// Built on a mis-read measurement (tools/ubench_mfma_valu.hip had its MFMA-only and VALU-only waves on different SIMDs):
-// the corrected one (tools/ubench_mfma_valu2.hip) shows that on gfx950 fp32 MFMAs and VALU work do NOT
-// overlap on a SIMD, whichever waves issue them — time is the SUM of both — so splitting the roles cannot win.  Kept
-// opt-in (MENTFLOW_BWD_WS=1) as the measured negative result: 15.8 ms against 11.2 ms for the generic kernel.
-//
-// Here the workgroup's 8 waves form 4 pairs; waves w and w+4 share a SIMD.  Wave w (< 4) is the MATRIX wave of pair w:
-// trunk recompute, output blocks phi_i = W3_i h3, gh += W3_i^T gphi_i, trunk backward, activation / pre-activation
-// stores.  Wave w+4 is the VECTOR wave: spline forward + adjoint of feature i, the gphi_i tile store.  They exchange
-// phi_i / gphi_i (32 values per lane) through two 8 KiB LDS slots per pair, software-pipelined one feature apart, with
-// one workgroup barrier per feature:
-//     step s :  M  reads gphi_{s-1} (slot s-1), gh += W3^T gphi_{s-1}, then writes phi_{s+1} into the same slot
-//               V  reads phi_s (slot s), spline adjoint, writes gphi_s back into slot s
-// To make room for the slots the last-layer blocks are staged COMPACT: block i keeps only the 2*kend3[i] (rounded to 8)
-// hidden columns its autoregressive mask leaves non-zero (92 KB instead of 137 KB for d = 6).
-constexpr int WS_SLOT = 2048 + 64;          // 32 slots x 64 lanes + one direct-gradient float per lane
-
-__device__ __forceinline__ int ws_blk_stride(const Sparsity& sp, int i) { return (2 * ((sp.kend3[i] + 3) & ~3)) | 1; }
-
-// The two roles are separate functions (separate register allocations: the kernel's VGPR count is the larger of the
-// two, not their union); both execute exactly 1 + d workgroup barriers per tile round.
-struct WsArgs {
-    const float* x;
-    const float* gy;
-    const float* glogp;
-    float* gx;
-    float* ACT;
-    float* GPRE;
-    float* GPHI;
-    int64_t n, ntiles, npad;
-    int d, offB3c;
-};
-
-template <int L>
-__device__ __forceinline__ void ws_matrix_wave(const float* lds, float* const (&slot)[2], const ImageLayout& g,
-                                               const WsArgs& a, const Sparsity& sp, int pair, int lane) {
-    const int col = lane & 31, hh = lane >> 5, d = a.d;
-#if !defined(MF_EMU) && defined(MF_WS_MPRIO)
-    __builtin_amdgcn_s_setprio(MF_WS_MPRIO);
-#endif
-    unsigned long long c_pro = 0, c_bar = 0, c_step = 0, c_epi = 0, c_m1 = 0, c_m2 = 0, c_m3 = 0, t0, t1;
-    for (int64_t base = (int64_t)blockIdx.x * 4; base < a.ntiles; base += (int64_t)gridDim.x * 4) {
-        MF_NO_HOIST();
-        t0 = WS_T();
-        const bool active = base + pair < a.ntiles;            // inactive pairs still walk the barriers
-        const int64_t tile = active ? base + pair : a.ntiles - 1;
-        const int64_t p = tile * 32 + col;
-        const bool valid = active && p < a.n;
-        const int64_t pc = (p < a.n) ? p : a.n - 1;
-        const float* xp = a.x + pc * d;
-        f32x16_t h[L][2];
-        f32x16_t gh[2];
-        f32x16_t gacc;
-        {
-            float xb[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) xb[s] = (2 * s + hh < d) ? xp[2 * s + hh] : 0.0f;
-            input_layer(lds + g.offW0, lds + g.offB0, g.S0, d, xb, h[0], col, hh);
-        }
-        if (active) store_tile(a.ACT, tile, col, hh, h[0]);
-#pragma unroll
-        for (int l = 1; l < L; ++l) {
-            const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
-            linear64(W, W + HID * WS, h[l - 1], h[l], col, hh, sp.kend_h[0], sp.kend_h[1]);
-            relu2(h[l]);
-            if (active) store_tile(a.ACT + (int64_t)l * a.npad * 64, tile, col, hh, h[l]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            gh[0][r] = 0.0f;
-            gh[1][r] = 0.0f;
-            gacc[r] = 0.0f;
-        }
-        {   // phi_0 -> slot 0
-            f32x16_t phi[2];
-            linear64s(lds + g.offW3, ws_blk_stride(sp, 0), lds + a.offB3c, h[L - 1], phi, col, hh, sp.kend3[0], sp.kend3[0]);
-#pragma unroll
-            for (int m = 0; m < 32; ++m) slot[0][m * 64 + lane] = phi[m >> 4][m & 15];
-        }
-        WS_ACC(c_pro, t0);
-        t0 = WS_T();
-        __syncthreads();
-        WS_ACC(c_bar, t0);
-        int woff_next = g.offW3 + HID * ws_blk_stride(sp, 0);   // compact offset of block s + 1
-        int woff_prev = g.offW3;                                 // compact offset of block s - 1
-#pragma unroll 1
-        for (int s = 0; s <= d; ++s) {
-            MF_NO_HOIST();
-            t0 = WS_T();
-            if (s >= 1) {
-                // gphi_{s-1} and the direct dL/dx_{s-1} from the vector wave
-                const int i = s - 1;
-                const float* sl = slot[i & 1];
-                float gv[32];
-                t1 = WS_T();
-#pragma unroll
-                for (int m = 0; m < 32; ++m) gv[m] = sl[m * 64 + lane];
-                const float gxd = sl[2048 + lane];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
-#if defined(MF_WS_DIAG) && !defined(MF_EMU)
-                asm volatile("" :: "v"(gv[0]), "v"(gv[31]));
-#endif
-                WS_ACC(c_m1, t1);
-                t1 = WS_T();
-                linear64s_t(lds + woff_prev, ws_blk_stride(sp, i), gv, gh, col, hh, sp.kend3[i] > 0, sp.rt1[i] != 0);
-#if defined(MF_WS_DIAG) && !defined(MF_EMU)
-                asm volatile("" :: "v"(gh[0][0]), "v"(gh[1][0]));
-#endif
-                WS_ACC(c_m2, t1);
-                woff_prev += HID * ws_blk_stride(sp, i);
-            }
-            if (s + 1 < d) {
-                t1 = WS_T();
-                f32x16_t phi[2];
-                linear64s(lds + woff_next, ws_blk_stride(sp, s + 1), lds + a.offB3c + (s + 1) * HID, h[L - 1], phi, col, hh,
-                          sp.kend3[s + 1], sp.kend3[s + 1]);
-                woff_next += HID * ws_blk_stride(sp, s + 1);
-                float* sl = slot[(s + 1) & 1];
-#pragma unroll
-                for (int m = 0; m < 32; ++m) sl[m * 64 + lane] = phi[m >> 4][m & 15];
-                WS_ACC(c_m3, t1);
-            }
-            WS_ACC(c_step, t0);
-            t0 = WS_T();
-            if (s < d) __syncthreads();
-            WS_ACC(c_bar, t0);
-        }
-        t0 = WS_T();
-        // ---- trunk backward
-#pragma unroll
-        for (int l = L - 1; l >= 1; --l) {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gh[rt][r] = (h[l][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
-            if (active) store_tile(a.GPRE + (int64_t)l * a.npad * 64, tile, col, hh, gh);
-            f32x16_t t[2];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                t[0][r] = 0.0f;
-                t[1][r] = 0.0f;
-            }
-            linear64_t(lds + g.offWh + (l - 1) * (HID * WS + HID), gh, t, col, hh, sp.kbeg_ht[0], sp.kbeg_ht[1]);
-            gh[0] = t[0];
-            gh[1] = t[1];
-        }
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gh[rt][r] = (h[0][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
-        if (active) store_tile(a.GPRE, tile, col, hh, gh);
-        if (a.gx != nullptr) {
-            const float* wcol = lds + g.offW0 + 4 * hh * g.S0 + col;
-#pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const int kk = 32 * (s >> 4) + rowmap(s & 15, 0);
-                const float w = (col < d) ? wcol[kk * g.S0] : 0.0f;
-                gacc = mfma(w, gh[s >> 4][s & 15], gacc);
-            }
-            if (valid) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * hh + j < d) a.gx[p * d + 4 * hh + j] = gacc[j];
-            }
-        }
-        WS_ACC(c_epi, t0);
-    }
-#if defined(MF_WS_DIAG) && !defined(MF_EMU)
-    if (pair == 0 && lane == 0) {
-        g_ws_diag[blockIdx.x * 16 + 0] = c_pro;
-        g_ws_diag[blockIdx.x * 16 + 1] = c_bar;
-        g_ws_diag[blockIdx.x * 16 + 2] = c_step;
-        g_ws_diag[blockIdx.x * 16 + 3] = c_epi;
-        g_ws_diag[blockIdx.x * 16 + 4] = c_m1;
-        g_ws_diag[blockIdx.x * 16 + 5] = c_m2;
-        g_ws_diag[blockIdx.x * 16 + 6] = c_m3;
-    }
-#endif
-}
-
-template <int K>
-__device__ __forceinline__ void ws_vector_wave(float* const (&slot)[2], const WsArgs& a, int pair, int lane) {
-    const int col = lane & 31, hh = lane >> 5, d = a.d;
-#if !defined(MF_EMU) && defined(MF_WS_VPRIO)
-    __builtin_amdgcn_s_setprio(MF_WS_VPRIO);
-#endif
-    unsigned long long c_pro = 0, c_bar = 0, c_step = 0, c_v1 = 0, c_v2 = 0, c_v3 = 0, t0, t1;
-    for (int64_t base = (int64_t)blockIdx.x * 4; base < a.ntiles; base += (int64_t)gridDim.x * 4) {
-        MF_NO_HOIST();
-        t0 = WS_T();
-        const bool active = base + pair < a.ntiles;
-        const int64_t tile = active ? base + pair : a.ntiles - 1;
-        const int64_t p = tile * 32 + col;
-        const bool valid = active && p < a.n;
-        const int64_t pc = (p < a.n) ? p : a.n - 1;
-        const float* xp = a.x + pc * d;
-        const float gl = valid ? -a.glogp[pc] : 0.0f;
-        // the particle's inputs and upstream gradients are fetched once per tile (not one exposed HBM round trip per
-        // feature) and picked by select chains
-        float xrow[FLOW_DMAX + 1], grow[FLOW_DMAX + 1];
-#pragma unroll
-        for (int j = 0; j < FLOW_DMAX + 1; ++j) {
-            xrow[j] = (j < d) ? xp[j] : 0.0f;
-            grow[j] = (valid && j < d) ? a.gy[pc * d + j] : 0.0f;
-        }
-        WS_ACC(c_pro, t0);
-        t0 = WS_T();
-        __syncthreads();
-        WS_ACC(c_bar, t0);
-#pragma unroll 1
-        for (int s = 0; s < d; ++s) {
-            MF_NO_HOIST();
-            t0 = WS_T();
-            float* sl = slot[s & 1];
-            float v[32], gv[32];
-#pragma unroll
-            for (int m = 0; m < 32; ++m) v[m] = sl[m * 64 + lane];
-            float xs = 0.0f, gyi = 0.0f;
-#pragma unroll
-            for (int j = 0; j < FLOW_DMAX + 1; ++j) {
-                xs = (j == s) ? xrow[j] : xs;
-                gyi = (j == s) ? grow[j] : gyi;
-            }
-            float yi, li, gxd;
-            t1 = WS_T();
-            rqs_apply<K, 1>(v, xs, hh, yi, li, gyi, gl, gv, gxd);
-#if defined(MF_WS_DIAG) && !defined(MF_EMU)
-            asm volatile("" :: "v"(gv[0]), "v"(gv[31]), "v"(gxd));
-#endif
-            WS_ACC(c_v1, t1);
-            t1 = WS_T();
-            if (active) store_tile(a.GPHI + (int64_t)s * a.npad * 64, tile, col, hh, gv);
-            WS_ACC(c_v2, t1);
-            t1 = WS_T();
-#pragma unroll
-            for (int m = 0; m < 32; ++m) sl[m * 64 + lane] = gv[m];
-            sl[2048 + lane] = gxd;
-            WS_ACC(c_v3, t1);
-            WS_ACC(c_step, t0);
-            t0 = WS_T();
-            __syncthreads();
-            WS_ACC(c_bar, t0);
-        }
-    }
-#if defined(MF_WS_DIAG) && !defined(MF_EMU)
-    if (pair == 0 && lane == 0) {
-        g_ws_diag[blockIdx.x * 16 + 8] = c_pro;
-        g_ws_diag[blockIdx.x * 16 + 9] = c_bar;
-        g_ws_diag[blockIdx.x * 16 + 10] = c_step;
-        g_ws_diag[blockIdx.x * 16 + 11] = c_v1;
-        g_ws_diag[blockIdx.x * 16 + 12] = c_v2;
-        g_ws_diag[blockIdx.x * 16 + 13] = c_v3;
-    }
-#endif
-}
-
-template <int K, int L>
-__global__ __launch_bounds__(FLOW_BLOCK) void rqs_layer_bwd_ws_kernel(const float* __restrict__ image, int d,
-                                                                      const float* __restrict__ x, int64_t n,
-                                                                      const float* __restrict__ gy,
-                                                                      const float* __restrict__ glogp,
-                                                                      float* __restrict__ gx, float* __restrict__ scratch,
-                                                                      Sparsity sp) {
-    MF_DYN_SMEM(float, lds);
-    const ImageLayout g = image_layout(d, L, d);
-    // ---- stage the image: trunk as is, last-layer blocks compacted to their non-zero columns
-    for (int i = threadIdx.x * 4; i < g.offW3; i += FLOW_BLOCK * 4)
-        *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(image + i);
-    int off = g.offW3;
-    for (int i = 0; i < d; ++i) {
-        const int st = ws_blk_stride(sp, i);
-        const int nc = st - 1;
-        for (int e = threadIdx.x; e < HID * nc; e += FLOW_BLOCK) {
-            const int r = e / nc, c = e - r * nc;
-            lds[off + r * st + c] = image[g.offW3 + (i * HID + r) * WS + c];
-        }
-        off += HID * st;
-    }
-    const int offB3c = off;
-    for (int e = threadIdx.x; e < d * HID; e += FLOW_BLOCK) lds[offB3c + e] = image[g.offB3 + e];
-    float* slots = lds + ((offB3c + d * HID + 3) & ~3);
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int pair = wid & 3;
-    float* const slot[2] = {slots + (2 * pair) * WS_SLOT, slots + (2 * pair + 1) * WS_SLOT};
-    WsArgs a;
-    a.x = x; a.gy = gy; a.glogp = glogp; a.gx = gx;
-    a.n = n; a.ntiles = (n + 31) / 32; a.npad = a.ntiles * 32;
-    a.ACT = scratch;
-    a.GPRE = a.ACT + (int64_t)L * a.npad * 64;
-    a.GPHI = a.GPRE + (int64_t)L * a.npad * 64;
-    a.d = d; a.offB3c = offB3c;
-    if (wid < 4) ws_matrix_wave<L>(lds, slot, g, a, sp, pair, lane);
-    else ws_vector_wave<K>(slot, a, pair, lane);
-}
-
 // =========================================================================================== inverse (density of a point)
 // x = T^-1(y) for one autoregressive layer (zuko AutoregressiveTransform._inverse: "x = 0; repeat d times
 // x = meta(x).inv(y)").  Feature of order t only depends on features of order < t, so the d passes are done in order:
@@ -1850,8 +1552,7 @@ extern "C" int64_t mf_flow_image_floats(int d, int hidden_layers) { return image
 // forces the choice where both are possible.
 static bool rqs_bwd_fused(int64_t n, int d, int hidden_layers, const int32_t* order, const Sparsity& sp, size_t* smem) {
     const char* e = getenv("MENTFLOW_BWD_FUSED");
-    const char* w = getenv("MENTFLOW_BWD_WS");
-    if ((e && atoi(e) == 0) || (w && atoi(w) == 1) || order == nullptr || d > FB_DMAX) return false;
+    if ((e && atoi(e) == 0) || order == nullptr || d > FB_DMAX) return false;
     if (!(e && atoi(e) == 1) && (n + 31) / 32 <= 4 * NUM_CU) return false;
     size_t fl = image_layout(d, hidden_layers, d).offW3;
     for (int i = 0; i < d; ++i) fl += (size_t)WS * (2 * ((sp.kend3[i] + 3) & ~3));
@@ -1912,32 +1613,6 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
     if (scratch_floats < mf_flow_bwd_scratch_floats(n, d, hidden_layers, order)) return fail("scratch too small");
     const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, d).total;
     bool launched = false;
-    // wave-specialised variant (matrix waves + vector waves): needs the mask structure (order) for the compact image
-    // (opt-in, MENTFLOW_BWD_WS=1: correct but measured slower than the generic kernel in round 1 — see DESIGN.md §6)
-    static const bool bwd_ws = [] { const char* e = getenv("MENTFLOW_BWD_WS"); return e && atoi(e) == 1; }();
-    if (bwd_ws && order != nullptr) {
-        const ImageLayout gl_ = image_layout(d, hidden_layers, d);
-        size_t fl = gl_.offW3;
-        for (int i = 0; i < d; ++i) fl += (size_t)HID * ((2 * ((sp.kend3[i] + 3) & ~3)) | 1);
-        fl += (size_t)d * HID;
-        fl = (fl + 3) & ~(size_t)3;
-        const size_t smem_ws = sizeof(float) * (fl + 8 * (size_t)WS_SLOT);
-        if (smem_ws <= 160 * 1024) {
-            const int64_t nt = (n + 31) / 32;
-            int64_t gws = (nt + 3) / 4;
-            if (gws > NUM_CU) gws = NUM_CU;
-#define XW(KK, LL)                                                                                                    \
-    if (!launched && bins == KK && hidden_layers == LL) {                                                             \
-        ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
-        MF_ALLOW_DYN_SMEM((rqs_layer_bwd_ws_kernel<KK, LL>), smem_ws);                                                \
-        MF_LAUNCH((rqs_layer_bwd_ws_kernel<KK, LL>), (int)gws, FLOW_BLOCK, smem_ws, stream, image, d, x, n, gy, glogp, \
-                  gx, scratch, sp);                                                                                   \
-        launched = true;                                                                                              \
-    }
-            MF_RQS_CASES(XW)
-#undef XW
-        }
-    }
     // fused backward + parameter gradients (no scratch traffic): 19.2 ms against 11.1 + 9.3 ms at 2 M particles (C4)
     {
         size_t smem_f = 0;
