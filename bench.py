@@ -103,9 +103,39 @@ def cpu_baseline(prob, budget_s: float = 20.0, n_cpu: int = 25_000):
         log(f"cpu_baseline: {steps} steps, {el:.1f} s")
         if el > budget_s or steps >= 50:
             break
-    return {"value": n_cpu * steps / el, "unit": "particle-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} train steps of {n_cpu} particles (reference batch size) on the same workload, "
-                      f"{el:.1f} s of CPU work; oracle = eager dense PyTorch restatement of the reference"}
+    out = {"value": n_cpu * steps / el, "unit": "particle-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{steps} train steps of {n_cpu} particles (reference batch size) on the same workload, "
+                     f"{el:.1f} s of CPU work; oracle = eager dense PyTorch restatement of the reference"}
+    out["parity"] = parity_gate(prob)
+    return out
+
+
+def parity_gate(prob, n: int = 36864):
+    """Same leg as the CPU baseline (the only place bench.py may touch the oracle): one loss + backward of the SAME model
+    on the GPU and in the oracle from one injected base draw (36 864 particles: the fused backward's size range), so
+    that the bench line carries the evidence that what was timed computes what the reference computes."""
+    from oracle.harness import oracle_step
+    model = prob.model
+    gen = model.generator
+    z = torch.randn(n, gen.features, generator=torch.Generator().manual_seed(4321))
+    dev = next(model.parameters()).device
+    saved = gen.inject_z
+    gen.inject_z = z.to(dev)
+    model.zero_grad()
+    L, H, D = model.loss(n)
+    L.backward()
+    g = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
+    gen.inject_z = saved
+    model.zero_grad()
+    Lo, Ho, Do, go = oracle_step(prob, z)
+    res = {"particles": n, "L_abs_err": abs(float(L) - float(Lo)), "H_abs_err": abs(float(H) - float(Ho)),
+           "D_max_abs_err": float((torch.stack(D).detach().cpu() - torch.stack(Do)).abs().max()),
+           "grad_max_err_over_max_grad": float((g - go).abs().max() / go.abs().max()), "L": float(Lo)}
+    mu = float(model.penalty_parameter)
+    res["ok"] = bool(res["L_abs_err"] < 1e-4 + mu * 2e-6 + 2e-5 * abs(float(Lo)) and res["H_abs_err"] < 1e-4
+                     and res["grad_max_err_over_max_grad"] < 2e-3)
+    log("parity gate: " + json.dumps(res))
+    return res
 
 
 def main():
