@@ -856,8 +856,8 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
     int off = g.offW3;
     for (int i = 0; i < d; ++i) {
         const int nc = fb_blk_cols(sp, i);
-        for (int e = threadIdx.x; e < HID * nc; e += FB_BLOCK) {
-            const int c = e >> 6, r = e & 63;
+        for (int e = threadIdx.x; e < HID * nc; e += FB_BLOCK) {        // coalesced reads along c, LDS writes stride WS
+            const int r = e / nc, c = e - r * nc;
             lds[off + c * WS + r] = image[g.offW3 + (i * HID + r) * WS + c];
         }
         off += nc * WS;
