@@ -1012,7 +1012,6 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 WS_ACC(c_[6], t0_);
                 t0_ = WS_T();
             }
-            WS_ACC(c_[7], t0_);
             t0_ = WS_T();
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -1112,10 +1111,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         WS_ACC(c_[10], t0_);
         WS_ACC(c_[11], tl_);
     }
-#if defined(MF_WS_DIAG) && !defined(MF_EMU)
-    if (threadIdx.x == 0)
-        for (int q = 0; q < 16; ++q) g_ws_diag[blockIdx.x * 16 + q] = c_[q];
-#endif
+    t0_ = WS_T();
     // ---- flush the accumulators (image coordinates)
 #pragma unroll
     for (int i = 0; i < FB_DMAX; ++i) {
@@ -1134,6 +1130,12 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
     }
     dw_flush(gimage + g.offW0, g.S0, d, hra, 0, lane, accT[0]);
     bias_flush(gimage + g.offB0, hra, lane, bsT[0]);
+#if defined(MF_WS_DIAG) && !defined(MF_EMU)
+    __builtin_amdgcn_s_waitcnt(0);
+    c_[7] = WS_T() - t0_;                                  // slot 7: the final flush, once per workgroup
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 16; ++q) g_ws_diag[blockIdx.x * 16 + q] = c_[q];
+#endif
 }
 
 // =========================================================================================== inverse (density of a point)
