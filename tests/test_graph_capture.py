@@ -12,11 +12,11 @@ from mentflow_amd.harness import build_problem
 pytestmark = pytest.mark.gpu
 
 
-def test_graphed_step_equals_eager_and_trains():
+@pytest.mark.parametrize("n", [25_000, 40_000])       # two-kernel backward / fused backward (> 32 768 particles)
+def test_graphed_step_equals_eager_and_trains(n):
     from mentflow_amd import _lib
     _lib.use_library(_lib.DEFAULT_PATH)
     dev = torch.device("cuda", 0)
-    n = 25_000
     prob = build_problem(ndim=6, num=25, bins=64, xmax=4.0, seed=2, transforms=5, prior_scale=1.0, device=dev,
                          dist_name="rings", meas_samples=200_000, penalty_parameter=100.0)
     model = prob.model
@@ -68,5 +68,5 @@ def test_graphed_step_equals_eager_and_trains():
     for _ in range(50):
         opt2.zero_grad(); L, H, D = model.loss(n); L.backward(); opt2.step()
     torch.cuda.synchronize(); t_eager = (time.perf_counter() - t0) / 50
-    print(f"\n25k-particle step: eager {t_eager*1e3:.2f} ms, graph replay {t_graph*1e3:.2f} ms")
+    print(f"\n{n}-particle step: eager {t_eager*1e3:.2f} ms, graph replay {t_graph*1e3:.2f} ms")
     assert t_graph < 1.5 * t_eager          # at 25 k particles the step is GPU-bound (~1.9 ms), replay only removes host time

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Development tool: A/B a compile-time flag.  Builds the library with extra hipcc flags (arg 1, may be empty), runs bench.py with
-# the remaining args as env assignments, prints the kernel times.  Usage: tools/ab_bench.sh "-DMF_PREFETCH" MENTFLOW_BWD_FUSED=0
+# the remaining args as env assignments, prints the kernel times.  Usage: tools/ab_bench.sh "-DSOME_FLAG" MENTFLOW_BWD_FUSED=0
+# NOTE: overwrites mentflow_amd/csrc/libmentflow_hip.so in the working copy it runs in (a scratch copy under gpurun);
+# rebuild with __graft_entry__.build() afterwards when used locally.
 set -e
 FLAGS="$1"; shift
 cd "$(dirname "$0")/.."
