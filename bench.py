@@ -47,6 +47,9 @@ WORKLOADS = {
     "c3": dict(ndim=6, num=25, bins=64, xmax=4.0, seed=2, transforms=5, prior_scale=1.0, dist_name="rings",
                optics="nd_1d", per_gpu=4_194_304,
                desc="rec_nd_1d rings d=6, 25 linear 1-D projections x 64 bins, NSF 5x[3x64] K=20"),
+    "c1": dict(ndim=2, num=7, bins=85, xmax=3.5, seed=21, transforms=5, prior_scale=1.0, dist_name="swissroll",
+               optics="2d_linear", gen_name="maf", per_gpu=50_000,
+               desc="rec_2d/linear swissroll d=2, 7 projections x 85 bins, MAF (affine) 5x[3x64], the reference's 50k batch"),
     "c2": dict(ndim=2, num=7, bins=85, xmax=3.5, seed=21, transforms=5, prior_scale=1.0, dist_name="swissroll",
                optics="2d_linear", per_gpu=1_048_576,
                desc="rec_2d/linear swissroll d=2, 7 projections x 85 bins, NSF 5x[3x64] K=20"),
@@ -200,7 +203,7 @@ def main():
 
     if rank == 0:
         d = w["ndim"]
-        lf = layer_flops(d)
+        lf = layer_flops(d, q=2 if w.get("gen_name") == "maf" else 59)      # MAF: shift + scale per feature
         T = w["transforms"]
         value = global_batch * args.steps / elapsed
         # dominant kernel by summed HIP-event time inside the timed region
