@@ -1526,6 +1526,191 @@ __global__ __launch_bounds__(64 * OA_MAX_WAVES) void outer_accum_kernel(const fl
     }
 }
 
+// =========================================================================================== backward, affine, fused
+// The MAF counterpart of rqs_layer_bwd_fused_kernel: same 4-wave workgroups, LDS staging of the parameter-gradient
+// operands and hand-scheduled chains; one output block (slot i of lane half 0 = shift_i, of half 1 = scale_i, all in
+// row tile 0), so the last-layer product is two 32 x 32 blocks (0, w & 1) with k split over the tile pairs (w >> 1).
+// The dense image fits LDS next to the staging areas for every d <= 7 (53 KB + 64 KB).
+template <int L>
+__global__ __launch_bounds__(FB_BLOCK) void affine_layer_bwd_fused_kernel(const float* __restrict__ image, int d,
+                                                                           const float* __restrict__ x, int64_t n,
+                                                                           const float* __restrict__ gy,
+                                                                           const float* __restrict__ glogp,
+                                                                           float* __restrict__ gx, float* __restrict__ gimage) {
+    MF_DYN_SMEM(float, lds);
+    const ImageLayout g = image_layout(d, L, 1);
+    stage_image<FB_BLOCK>(lds, image, g.total);
+    float* SA = lds + ((g.total + 3) & ~3);
+    float* SB = SA + 4 * FB_TILE;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+    const StageLane sl = stage_lane(col, hh);
+    float* myA = SA + wid * FB_TILE;
+    float* myB = SB + wid * FB_TILE;
+    const int fra = wid >> 1, frb = wid & 1;              // full 64 x 64 product
+    const int hra = wid & 1, ht0 = 2 * (wid >> 1);        // single column / row tile, k split over tile pairs
+    constexpr int DM = FLOW_DMAX + 1;
+
+    f32x16_t accO, accT[L];
+    float bsO = 0.0f, bsT[L];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accO[r] = 0.0f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        bsT[l] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accT[l][r] = 0.0f;
+    }
+    const int64_t ntiles = (n + 31) / 32;
+    const int64_t ngroups = (ntiles + 3) / 4;
+    float xn[DM], gyn[DM], gln;
+    auto load_rows = [&](int64_t grp2, float (&xo)[DM], float (&go)[DM], float& glo) {
+        const int64_t p2 = (grp2 * 4 + wid) * 32 + col;
+        const bool v2 = p2 < n;
+        const int64_t pc2 = v2 ? p2 : n - 1;
+#pragma unroll
+        for (int j = 0; j < DM; ++j) {
+            xo[j] = (j < d) ? x[pc2 * d + j] : 0.0f;
+            go[j] = (v2 && j < d) ? gy[pc2 * d + j] : 0.0f;
+        }
+        glo = v2 ? -glogp[pc2] : 0.0f;
+    };
+    load_rows(blockIdx.x, xn, gyn, gln);
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        MF_NO_HOIST();
+        const int64_t p = (grp * 4 + wid) * 32 + col;
+        const bool valid = p < n;
+        float xr[DM], gyr[DM];
+#pragma unroll
+        for (int j = 0; j < DM; ++j) {
+            xr[j] = xn[j];
+            gyr[j] = gyn[j];
+        }
+        const float gl = gln;
+        {
+            const int64_t gnext = grp + gridDim.x;
+            load_rows(gnext < ngroups ? gnext : grp, xn, gyn, gln);
+        }
+        float xb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xb[s] = hh ? xr[2 * s + 1] : xr[2 * s];
+        // ---- trunk (h[0] is recomputed later instead of kept)
+        f32x16_t h[L][2];
+        {
+            f32x16_t h0[2];
+            input_layer4(lds + g.offW0, lds + g.offB0, g.S0, xb, h0, col, hh);
+#pragma unroll
+            for (int l = 1; l < L; ++l) {
+                const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    h[l][rt] = bias_tile(W + HID * WS, rt, hh);
+                    chain64<1>(h[l][rt], W + (32 * rt + col) * WS + 4 * hh, 0, 8, BTile{l == 1 ? h0 : h[l - 1]});
+                }
+                relu2(h[l]);
+            }
+            if (L == 1) { h[0][0] = h0[0]; h[0][1] = h0[1]; }
+        }
+        __syncthreads();                                   // the previous group's last product has read S_A / S_B
+        stage_tile(myB, sl, h[L - 1]);
+        // ---- output block (row tile 0 only) and the affine adjoint
+        const float* W3 = lds + g.offW3;
+        f32x16_t phi = bias_tile(lds + g.offB3, 0, hh);
+        chain64<1>(phi, W3 + col * WS + 4 * hh, 0, 8, BTile{h[L - 1]});
+        f32x16_t gacc;
+        float gv[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gacc[r] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) gv[m] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DM; ++i) {
+            if (i < d) {
+                const float mine = phi[i];
+                const float other = __shfl_xor(mine, 32);
+                const float scale = hh ? mine : other;
+                const float ls = soft_clip(scale, LOG_SLOPE_INV);
+                const float e = fast_exp(ls);
+                const float gyi = gyr[i];
+                const float gls = fmaf(gyi * xr[i], e, gl);               // dL/ds~ : through y and through ladj
+                gv[i] = hh ? gls * soft_clip_grad(scale, LOG_SLOPE_INV) : gyi;
+                const float gxd = gyi * e;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
+            }
+        }
+        stage_tile(myA, sl, gv);
+        __syncthreads();
+        dw_accum(SA, SB, 0, frb, ht0, 1, true, frb == 0 ? -1 : 99, lane, accO, bsO);
+        // gh = W3^T gphi: only the 16 slots of row tile 0 are populated (k-step groups 0..3)
+        f32x16_t gh[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gh[rt][r] = 0.0f;
+            chain64<WS>(gh[rt], W3 + 4 * hh * WS + 32 * rt + col, 0, 4, BVec{gv});
+        }
+        // ---- trunk backward
+#pragma unroll
+        for (int l = L - 1; l >= 1; --l) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gh[rt][r] = (h[l][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
+            if (l == 1) input_layer4(lds + g.offW0, lds + g.offB0, g.S0, xb, h[0], col, hh);
+            __syncthreads();
+            stage_tile(myA, sl, gh);
+            stage_tile(myB, sl, h[l - 1]);
+            __syncthreads();
+            dw_accum(SA, SB, fra, frb, 0, 2, true, frb, lane, accT[l], bsT[l]);
+            f32x16_t t[2];
+            const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[rt][r] = 0.0f;
+                chain64<WS>(t[rt], W + 4 * hh * WS + 32 * rt + col, 0, 8, BTile{gh});
+            }
+            gh[0] = t[0];
+            gh[1] = t[1];
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gh[rt][r] = (h[0][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
+        __syncthreads();
+        stage_tile(myA, sl, gh);
+        if (hh == 0) {
+#pragma unroll
+            for (int j = 0; j < DM; ++j)
+                if (j < d) myB[j * 32 + ((((col >> 2) ^ (j >> 1)) & 7) << 2) + (col & 3)] = xr[j];
+        }
+        __syncthreads();
+        dw_accum(SA, SB, hra, 0, ht0, 1, true, -1, lane, accT[0], bsT[0]);
+        if (gx != nullptr) {
+            const float* wcol = lds + g.offW0 + 4 * hh * g.S0 + col;
+            if (g.S0 == 7) chain64<7>(gacc, wcol, 0, 8, BTile{gh});
+            else if (g.S0 == 5) chain64<5>(gacc, wcol, 0, 8, BTile{gh});
+            else if (g.S0 == 3) chain64<3>(gacc, wcol, 0, 8, BTile{gh});
+            else chain64<1>(gacc, wcol, 0, 8, BTile{gh});
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * hh + j < d) gx[p * d + 4 * hh + j] = gacc[j];
+            }
+        }
+    }
+    dw_flush(gimage + g.offW3, WS, HID, 0, frb, lane, accO);
+    if (frb == 0) bias_flush(gimage + g.offB3, 0, lane, bsO);
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        float* gW = gimage + g.offWh + (l - 1) * (HID * WS + HID);
+        dw_flush(gW, WS, HID, fra, frb, lane, accT[l]);
+        bias_flush(gW + HID * WS, fra, lane, bsT[l]);
+    }
+    dw_flush(gimage + g.offW0, g.S0, d, hra, 0, lane, accT[0]);
+    bias_flush(gimage + g.offB0, hra, lane, bsT[0]);
+}
+
 static int flow_check(int d, int L, int64_t n) {
     if (d < 1 || d > FLOW_DMAX) return fail("flow kernels support 1 <= d <= %d (got %d)", FLOW_DMAX, d);
     if (L < 1) return fail("hidden_layers must be >= 1");
@@ -1679,7 +1864,16 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
 // ------------------------------------------------------------------------------------------------ affine C ABI
 extern "C" int64_t mf_flow_affine_image_floats(int d, int hidden_layers) { return image_layout(d, hidden_layers, 1).total; }
 
+// the fused affine backward needs no mask structure (dense image, 117 KB of LDS for every d <= 7); same batch-size
+// threshold and MENTFLOW_BWD_FUSED override as the spline layers
+static bool affine_bwd_fused(int64_t n) {
+    const char* e = getenv("MENTFLOW_BWD_FUSED");
+    if (e && atoi(e) == 0) return false;
+    return (e && atoi(e) == 1) || (n + 31) / 32 > 4 * NUM_CU;
+}
+
 extern "C" int64_t mf_flow_affine_bwd_scratch_floats(int64_t n, int hidden_layers) {
+    if (affine_bwd_fused(n)) return 0;
     const int64_t npad = ((n + 31) / 32) * 32;
     return (2 * (int64_t)hidden_layers + 1) * npad * 64;
 }
@@ -1715,6 +1909,23 @@ extern "C" int mf_flow_affine_layer_bwd(const float* image, int d, int hidden_la
     const Sparsity sp = make_sparsity(d, order, 1);
     const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, 1).total;
     bool launched = false;
+    if (affine_bwd_fused(n)) {
+        const size_t smem_f = sizeof(float) * ((((size_t)image_layout(d, hidden_layers, 1).total + 3) & ~(size_t)3) + 8 * (size_t)FB_TILE);
+        const int64_t ngroups = ((n + 31) / 32 + 3) / 4;
+        const int gf = (int)(ngroups > NUM_CU ? NUM_CU : ngroups);
+#define XF(LL)                                                                                                        \
+    if (!launched && hidden_layers == LL) {                                                                           \
+        ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
+        MF_ALLOW_DYN_SMEM((affine_layer_bwd_fused_kernel<LL>), smem_f);                                               \
+        MF_LAUNCH((affine_layer_bwd_fused_kernel<LL>), gf, FB_BLOCK, smem_f, stream, image, d, x, n, gy, glogp, gx,    \
+                  gimage);                                                                                            \
+        launched = true;                                                                                              \
+    }
+        MF_AFFINE_CASES(XF)
+#undef XF
+        if (launched) return check_launch("mf_flow_affine_layer_bwd(fused)");
+        return fail("no affine kernel instance for hidden_layers=%d (built: 2, 3)", hidden_layers);
+    }
 #define X(LL)                                                                                                         \
     if (!launched && hidden_layers == LL) {                                                                           \
         ProfScope prof(PK_FLOW_BWD, stream);                                                                          \

@@ -121,7 +121,10 @@ class FlowSampleFn(torch.autograd.Function):
                 chunk = n                       # fused backward: no hand-off scratch, one launch per layer
             scratch_floats = need(chunk)
         else:
-            scratch_floats = _lib.get_lib().mf_flow_affine_bwd_scratch_floats(chunk, spec.L)
+            lib = _lib.get_lib()
+            if lib.mf_flow_affine_bwd_scratch_floats(n, spec.L) == 0:
+                chunk = n                       # fused backward: no hand-off scratch
+            scratch_floats = lib.mf_flow_affine_bwd_scratch_floats(chunk, spec.L)
         scratch = torch.empty(max(scratch_floats, 1), dtype=_F32, device=dev)
         g = gx
         for t in reversed(range(spec.T)):
