@@ -17,27 +17,36 @@ def _sphere_surface_area(r=1.0, d=3):
     return factor * (r ** (d - 1))
 
 
+def _unit_std(a: np.ndarray) -> np.ndarray:
+    """Every column scaled to unit standard deviation, in place for float arrays (the reference's `x /= np.std(x, 0)`)."""
+    a /= a.std(axis=0)
+    return a
+
+
 class Distribution:
+    """Seeded sampler: `_sample` draws the raw cloud, `sample_np` adds the reference's post-processing (one permutation,
+    then optional Gaussian noise — in this order, from the same generator: the golden fixtures pin the stream)."""
+
     default_noise = None
 
     def __init__(self, ndim: int = 2, seed: int = None, noise: float = None, shuffle: bool = True) -> None:
         self.ndim, self.seed, self.shuffle = ndim, seed, shuffle
+        self.noise = noise if noise is not None else self.default_noise
         self.rng = np.random.default_rng(seed)
-        self.noise = self.default_noise if noise is None else noise
 
     def _sample(self, size: int) -> np.ndarray:
-        raise NotImplementedError
+        raise NotImplementedError(type(self).__name__)
 
     def sample_np(self, size: int) -> np.ndarray:
-        x = self._sample(int(size))
+        cloud = self._sample(int(size))
         if self.shuffle:
-            x = self.rng.permutation(x)
+            cloud = self.rng.permutation(cloud)
         if self.noise:
-            x = x + self.rng.normal(scale=self.noise, size=x.shape)
-        return x
+            cloud = cloud + self.rng.normal(scale=self.noise, size=cloud.shape)
+        return cloud
 
     def sample(self, size: int) -> torch.Tensor:
-        return torch.from_numpy(self.sample_np(size)).type(torch.float32)
+        return torch.from_numpy(self.sample_np(size)).to(torch.float32)
 
 
 class Gaussian(Distribution):
@@ -46,16 +55,19 @@ class Gaussian(Distribution):
 
 
 class KV(Distribution):
+    """Uniform on the unit sphere surface, columns rescaled to unit standard deviation."""
+
     default_noise = 0.05
 
     def _sample(self, size):
-        x = self.rng.normal(size=(size, self.ndim))
-        x /= np.linalg.norm(x, axis=1)[:, None]
-        x /= np.std(x, axis=0)
-        return x
+        g = self.rng.normal(size=(size, self.ndim))
+        g /= np.linalg.norm(g, axis=1, keepdims=True)
+        return _unit_std(g)
 
 
 class Rings(Distribution):
+    """Concentric KV shells; populations ~ surface area x a linear decay factor (outer shell = `decay`)."""
+
     default_noise = 0.15
 
     def __init__(self, n_rings: int = 2, decay: float = 0.5, **kws) -> None:
@@ -64,31 +76,30 @@ class Rings(Distribution):
 
     def _sample(self, size):
         radii = np.linspace(1.0, 0.0, self.n_rings, endpoint=False)[::-1]
-        sizes = np.array([_sphere_surface_area(d=self.ndim, r=r) for r in radii])
-        sizes = sizes * np.linspace(1.0, self.decay, self.n_rings)
-        sizes = (sizes * (size / np.sum(sizes))).astype(int)
-        dist = KV(ndim=self.ndim, seed=self.seed)
-        x = [(radius * dist.sample(s)).numpy() for s, radius in zip(sizes, radii)]   # float32, as the reference
-        x = np.vstack(x)
-        x /= np.std(x, axis=0)
-        return x
+        weights = np.array([_sphere_surface_area(r=r, d=self.ndim) for r in radii]) * np.linspace(1.0, self.decay, self.n_rings)
+        counts = (weights * (size / weights.sum())).astype(int)
+        shell = KV(ndim=self.ndim, seed=self.seed)          # ONE sampler for all shells: its stream continues
+        parts = [(r * shell.sample(c)).numpy() for c, r in zip(counts, radii)]        # float32, as the reference
+        return _unit_std(np.vstack(parts))
 
 
 class GaussianMixture(Distribution):
+    """`modes` isotropic Gaussians with centres drawn uniformly in [-xmax, xmax]^d at construction."""
+
     def __init__(self, modes: int = 7, xmax: float = 3.0, scale: float = 0.75, shiftscale=True, **kws) -> None:
         super().__init__(**kws)
-        self.modes = modes
-        self.locs = self.rng.uniform(-xmax, xmax, size=(self.modes, self.ndim))
-        self.scales = scale * np.ones(self.modes)
-        self.shiftscale = shiftscale
+        self.modes, self.shiftscale = modes, shiftscale
+        self.locs = self.rng.uniform(-xmax, xmax, size=(modes, self.ndim))
+        self.scales = np.full(modes, scale, dtype=np.float64)
 
     def _sample(self, size):
-        x = np.vstack([self.rng.normal(loc=loc, scale=scale, size=(size // self.modes, self.ndim))
-                       for scale, loc in zip(self.scales, self.locs)])
+        per_mode = size // self.modes
+        cloud = np.vstack([self.rng.normal(loc=centre, scale=width, size=(per_mode, self.ndim))
+                           for width, centre in zip(self.scales, self.locs)])
         if self.shiftscale:
-            x = x - np.mean(x, axis=0)
-            x = x / np.std(x, axis=0)
-        return x
+            cloud = cloud - cloud.mean(axis=0)
+            cloud = cloud / cloud.std(axis=0)
+        return cloud
 
 
 class SwissRoll(Distribution):
@@ -96,9 +107,7 @@ class SwissRoll(Distribution):
 
     def _sample(self, size):
         t = 1.5 * np.pi * (1.0 + 2.0 * self.rng.uniform(0.0, 1.0, size=size))
-        x = np.stack([t * np.cos(t), t * np.sin(t)], axis=-1)
-        x /= np.std(x, axis=0)
-        return x
+        return _unit_std(np.stack([t * np.cos(t), t * np.sin(t)], axis=-1))
 
 
 DISTRIBUTIONS = {"gaussian": Gaussian, "kv": KV, "rings": Rings, "gaussian_mixture": GaussianMixture,
@@ -106,6 +115,8 @@ DISTRIBUTIONS = {"gaussian": Gaussian, "kv": KV, "rings": Rings, "gaussian_mixtu
 
 
 def get_distribution(name: str, **kws) -> Distribution:
-    if name not in DISTRIBUTIONS:
-        raise NotImplementedError(f"distribution '{name}' is not restated (built: {sorted(DISTRIBUTIONS)})")
-    return DISTRIBUTIONS[name](**kws)
+    try:
+        cls = DISTRIBUTIONS[name]
+    except KeyError:
+        raise NotImplementedError(f"distribution '{name}' is not restated (built: {sorted(DISTRIBUTIONS)})") from None
+    return cls(**kws)

@@ -8,20 +8,21 @@ from .prior import Gaussian
 
 
 class EntropyEstimator(torch.nn.Module):
-    """Estimates negative entropy from samples and/or log probability."""
+    """Negative-entropy estimate H from samples and / or their log-density (interface of entropy.py:8-15); `prior`
+    turns it into the relative entropy against that prior."""
 
     def __init__(self, prior: Any = None) -> None:
         super().__init__()
         self.prior = prior
 
-    def forward(self, x: torch.Tensor, log_prob: torch.Tensor = None) -> torch.Tensor:
-        raise NotImplementedError
+    def forward(self, x: torch.Tensor, log_prob: Optional[torch.Tensor] = None) -> torch.Tensor:
+        raise NotImplementedError(type(self).__name__)
 
 
 class EmptyEntropyEstimator(EntropyEstimator):
-    """Returns zero (entropy.py:18-24)."""
+    """No entropy term (entropy.py:18-24): the python float 0.0, whatever the inputs."""
 
-    def forward(self, x: torch.Tensor, log_prob: torch.Tensor = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, log_prob: Optional[torch.Tensor] = None) -> float:
         return 0.0
 
 

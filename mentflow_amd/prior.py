@@ -1,4 +1,4 @@
-"""Prior distributions — mirrors mentflow/prior.py:4-26."""
+"""Prior distributions (interface of mentflow/prior.py:4-26)."""
 import math
 
 import torch
@@ -10,16 +10,15 @@ class Gaussian:
     sufficient statistic sum|x|^2 is needed, which the entropy kernel reduces."""
 
     def __init__(self, ndim: int = 2, scale: float = 1.0, device=None) -> None:
-        self.ndim = ndim
-        self.scale = scale
-        self.device = device
+        self.ndim, self.scale, self.device = int(ndim), float(scale), device
 
-    def to(self, device):
+    def to(self, device) -> "Gaussian":
         self.device = device
         return self
 
     def log_norm(self) -> float:
-        return -self.ndim * math.log(self.scale) - 0.5 * self.ndim * math.log(2.0 * math.pi)
+        """log of the normalisation constant (2 pi scale^2)^(-ndim/2)."""
+        return -self.ndim * (math.log(self.scale) + 0.5 * math.log(2.0 * math.pi))
 
     def log_prob(self, x: torch.Tensor) -> torch.Tensor:
-        return -0.5 * torch.sum(x * x, dim=1) / (self.scale ** 2) + self.log_norm()
+        return self.log_norm() - 0.5 * x.square().sum(dim=1) / self.scale ** 2

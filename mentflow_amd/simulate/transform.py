@@ -11,17 +11,19 @@ from .. import ops
 
 
 def rotation_matrix(angle: float) -> torch.Tensor:
-    """transform.py:12-15."""
-    _cos, _sin = np.cos(angle), np.sin(angle)
-    return torch.tensor([[_cos, _sin], [-_sin, _cos]])
+    """2 x 2 phase-space rotation [[c, s], [-s, c]] in float64, like transform.py:12-15 (numpy scalars)."""
+    c, s = float(np.cos(angle)), float(np.sin(angle))
+    return torch.tensor([[c, s], [-s, c]], dtype=torch.float64)
 
 
 class Transform(nn.Module):
+    """Interface of a transport map: ``forward`` (x -> u) and ``inverse`` (u -> x)."""
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError
+        raise NotImplementedError(f"{type(self).__name__}.forward")
 
     def inverse(self, u: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError
+        raise NotImplementedError(f"{type(self).__name__}.inverse")
 
 
 class LinearTransform(Transform):
@@ -33,31 +35,30 @@ class LinearTransform(Transform):
 
     def __init__(self, matrix: torch.Tensor) -> None:
         super().__init__()
+        self.matrix = self.matrix_inv = None
         self.set_matrix(matrix)
 
     def set_matrix(self, matrix: torch.Tensor) -> None:
-        self.matrix = matrix
-        self.matrix_inv = torch.linalg.inv(matrix)
+        self.matrix, self.matrix_inv = matrix, torch.linalg.inv(matrix)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return torch.matmul(x, self.matrix.T)
+        return x @ self.matrix.T
 
     def inverse(self, u: torch.Tensor) -> torch.Tensor:
-        return torch.matmul(u, self.matrix_inv.T)
+        return u @ self.matrix_inv.T
 
     def to(self, device):
-        self.matrix = self.matrix.to(device)
-        self.matrix_inv = self.matrix_inv.to(device)     # the reference forgets this one (transform.py:73-75)
+        # plain attributes, not buffers (the reference moves `matrix` only and leaves `matrix_inv` behind)
+        self.matrix, self.matrix_inv = self.matrix.to(device), self.matrix_inv.to(device)
         return self
 
 
-def reverse_momentum(x):
-    """transform.py:18-21, on a copy (the reference flips the momenta of its argument in place, so its
-    MultipoleTransform.inverse(u) also changes the caller's u; the returned value is the same)."""
-    x = x.clone()
-    for i in range(0, x.shape[1], 2):
-        x[:, i + 1] *= -1.0
-    return x
+def reverse_momentum(x: torch.Tensor) -> torch.Tensor:
+    """Momenta (odd columns) negated, on a copy.  transform.py:18-21 flips them in place, so the reference's
+    MultipoleTransform.inverse(u) also changes the caller's u; the returned value is the same."""
+    out = x.clone()
+    out[:, 1::2].neg_()
+    return out
 
 
 class MultipoleTransform(Transform):
@@ -81,25 +82,25 @@ class MultipoleTransform(Transform):
 
 
 class CompositeTransform(Transform):
-    """transform.py:35-55."""
+    """Chain of transforms applied left to right (transform.py:35-55); ``transforms`` is an ``nn.Sequential`` like the
+    reference's, so ``len`` / indexing / iteration work the same.  ``simulate.forward`` peels a trailing LinearTransform
+    off the chain and fuses it into the projection kernel."""
 
     def __init__(self, *transforms) -> None:
         super().__init__()
         self.transforms = nn.Sequential(*transforms)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        u = x
-        for transform in self.transforms:
-            u = transform(u)
-        return u
-
-    def inverse(self, u: torch.Tensor) -> torch.Tensor:
-        x = u
-        for transform in list(self.transforms)[::-1]:
-            x = transform.inverse(x)
+        for stage in self.transforms:
+            x = stage(x)
         return x
 
+    def inverse(self, u: torch.Tensor) -> torch.Tensor:
+        for stage in reversed(list(self.transforms)):
+            u = stage.inverse(u)
+        return u
+
     def to(self, device):
-        for transform in self.transforms:
-            transform.to(device)
+        for stage in self.transforms:
+            stage.to(device)
         return self
