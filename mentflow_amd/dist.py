@@ -33,13 +33,18 @@ def init_from_env(backend: Optional[str] = None, seed: Optional[int] = None) -> 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
+    # rehearsal on a one-GPU box: MENTFLOW_SHARE_GPU=1 puts every rank on cuda:0 and talks gloo (RCCL refuses two ranks
+    # on one device); the production path is one rank per GPU over RCCL
+    share = use_gpu and os.environ.get("MENTFLOW_SHARE_GPU") == "1"
+    if share:
+        local, backend = 0, backend or "gloo"
     if use_gpu:
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"),
-                                **({"device_id": device} if use_gpu else {}))
+        backend = backend or ("nccl" if use_gpu else "gloo")
+        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
     if seed is not None:
         torch.manual_seed(seed + rank())      # every rank draws its own particles
     return device
