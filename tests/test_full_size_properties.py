@@ -46,7 +46,7 @@ def test_c4_histograms_additive_normalised_and_chunk_invariant(dev):
     torch.testing.assert_close(one, ghat[7], rtol=1e-6, atol=1e-9)
 
 
-def test_c3_flow_roundtrip_logprob_and_chunked_backward(dev):
+def test_c3_flow_roundtrip_logprob_and_chunked_backward(dev, monkeypatch):
     """C3/C4 flow: 6-D NSF 5 x [3 x 64], K = 20; 1 048 576 particles."""
     torch.manual_seed(0)
     gen = mf.generate.build_generator("nsf", device=dev, input_features=6, output_features=6, hidden_layers=3,
@@ -71,17 +71,21 @@ def test_c3_flow_roundtrip_logprob_and_chunked_backward(dev):
     # logp = logN(z) - ladj  =>  ladj = logN(z) - logp
     ladj = (-0.5 * (z ** 2).sum(1) - 3 * 1.8378770664093453) - lp
     assert torch.isfinite(ladj).all()
-    # backward: chunk size must not change the gradients (scratch reuse, tile padding, atomics)
+    # backward: neither the variant (fused kernel, one launch per layer / two kernels with a scratch hand-off) nor the
+    # chunk size of the two-kernel path (scratch reuse, tile padding, atomics) may change the gradients
     w = torch.randn(n, 6, device=dev)
     grads = []
-    for chunk in (1 << 19, 100_003):
+    for fused, chunk in (("1", 1 << 19), ("0", 1 << 19), ("0", 100_003)):
+        monkeypatch.setenv("MENTFLOW_BWD_FUSED", fused)
         gen.spec().bwd_chunk = chunk
         gen.zero_grad()
         xx, ll = gen.sample_and_log_prob(n, z=z)
         ((xx * w).sum() / n + ll.mean()).backward()
         grads.append(torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).clone())
+    monkeypatch.delenv("MENTFLOW_BWD_FUSED")
     gen.spec().bwd_chunk = 1 << 19
-    torch.testing.assert_close(grads[0], grads[1], rtol=2e-4, atol=2e-5 * float(grads[0].abs().max()))
+    for other in grads[1:]:
+        torch.testing.assert_close(grads[0], other, rtol=2e-4, atol=2e-5 * float(grads[0].abs().max()))
     # linearity of the backward in the upstream gradient
     gen.zero_grad()
     xx, ll = gen.sample_and_log_prob(n, z=z)
