@@ -132,6 +132,7 @@ __global__ __launch_bounds__(KDE_BLOCK) void acc_to_float_kernel(const double* _
 // CH (1, 2, 4 or 8) adjacent lanes share a particle and take every CH-th projection; their partial gradient rows are
 // summed with a fixed butterfly (deterministic, no atomics).  Small batches use CH > 1: one lane per particle walks
 // all P projections serially, which leaves most of the chip idle at the reference's 25 000-particle batch.
+template <int RT>   // RT > 0: compile-time window radius (unrolled, branch-free);  RT == 0: runtime radius
 __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V, int P, int Pg,
     const float* __restrict__ coords, int B, float inv_sigma, int R, const float* __restrict__ gS,
@@ -162,11 +163,23 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
             const float u = project(xv, Vl + q * d, d);
             const int kc = centre_bin(u, c0, inv_delta, B, R);
             float du = 0.0f;
-            for (int j = -R; j <= R; ++j) {
-                const int k = kc + j;
-                if (k >= 0 && k < B) {
-                    const float r = (u - cl[k]) * inv_sigma;
-                    du = fmaf(img[q * B + k] * gauss_weight(r), -r * inv_sigma, du);
+            if (RT > 0) {
+                // window bins outside [0, B) read a clamped bin with weight 0: no divergent branch in the unrolled loop
+#pragma unroll
+                for (int j = -RT; j <= RT; ++j) {
+                    const int k = kc + j;
+                    const int kk = min(max(k, 0), B - 1);
+                    const float r = (u - cl[kk]) * inv_sigma;
+                    const float g = (k == kk) ? img[q * B + kk] : 0.0f;
+                    du = fmaf(g * gauss_weight(r), -r * inv_sigma, du);
+                }
+            } else {
+                for (int j = -R; j <= R; ++j) {
+                    const int k = kc + j;
+                    if (k >= 0 && k < B) {
+                        const float r = (u - cl[k]) * inv_sigma;
+                        du = fmaf(img[q * B + k] * gauss_weight(r), -r * inv_sigma, du);
+                    }
                 }
             }
 #pragma unroll
@@ -697,9 +710,15 @@ extern "C" int mf_proj_kde1d_bwd(const float* x, int64_t n, int d, const float* 
     while (CH < 8 && CH * 2 <= P && (n * CH + KDE_BLOCK - 1) / KDE_BLOCK < 4 * NUM_CU) CH *= 2;
     const int64_t G = (n * CH + KDE_BLOCK - 1) / KDE_BLOCK;
     ProfScope prof(PK_KDE1D_BWD, stream);
-    MF_ALLOW_DYN_SMEM(proj_kde1d_bwd_kernel, smem);
-    MF_LAUNCH(proj_kde1d_bwd_kernel, dim3((unsigned)G), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
-              1.0f / sigma, R, gS, gx, accumulate, CH);
+    if (R == 4) {
+        MF_ALLOW_DYN_SMEM(proj_kde1d_bwd_kernel<4>, smem);
+        MF_LAUNCH(proj_kde1d_bwd_kernel<4>, dim3((unsigned)G), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
+                  1.0f / sigma, R, gS, gx, accumulate, CH);
+    } else {
+        MF_ALLOW_DYN_SMEM(proj_kde1d_bwd_kernel<0>, smem);
+        MF_LAUNCH(proj_kde1d_bwd_kernel<0>, dim3((unsigned)G), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
+                  1.0f / sigma, R, gS, gx, accumulate, CH);
+    }
     return check_launch("mf_proj_kde1d_bwd");
 }
 
