@@ -65,6 +65,26 @@ class MENTFlow(nn.Module):
         return [self.discrepancy_function(pred, meas)
                 for pred, meas in zip(unravel(predictions), unravel(self.measurements))]
 
+    # ------------------------------------------------------------------ data-parallel gradient reduction
+    def _wire_gradient_reduction(self) -> None:
+        """The forward all-reduce of the histogram sums has the IDENTITY as its adjoint (mentflow_amd/dist.py), which
+        is only right if the per-rank parameter gradients are summed afterwards.  Flow generators expose a
+        ``grad_reduce`` slot called once on their flat gradient (one all-reduce per step); any other generator (the
+        NN baseline) gets a post-accumulate hook per parameter that all-reduces ``p.grad``.  Wired once per generator."""
+        gen = self.generator
+        if getattr(gen, "_mf_dp_wired", False):
+            return
+        if "grad_reduce" in vars(gen) or hasattr(type(gen), "grad_reduce"):
+            if gen.grad_reduce is None:
+                gen.grad_reduce = mfdist.reduce_gradients_
+        else:
+            params = [p for p in gen.parameters() if p.requires_grad]
+            if not params:
+                raise NotImplementedError("data-parallel training needs a generator with trainable parameters")
+            for p in params:
+                p.register_post_accumulate_grad_hook(lambda q: mfdist.reduce_gradients_(q.grad))
+        gen._mf_dp_wired = True
+
     # ------------------------------------------------------------------ fused step
     def _fused_plan(self):
         """Static launch plan of the fused loss: one entry per distinct diagnostic object (the reference shares ONE
@@ -112,15 +132,13 @@ class MENTFlow(nn.Module):
         groups, n_meas, kind = plan
         n_total = int(batch_size)
         n_local = mfdist.local_batch(n_total)
-        if mfdist.is_active() and getattr(self.generator, "grad_reduce", None) is None:
-            self.generator.grad_reduce = mfdist.reduce_gradients_
+        if mfdist.is_active():
+            self._wire_gradient_reduction()
         x, log_prob = self.generator.sample_and_log_prob(n_local)
 
         use_entropy = isinstance(self.entropy_estimator, MonteCarloEntropyEstimator)
         if use_entropy and log_prob is None:
             raise ValueError("the Monte-Carlo entropy estimator needs a generator with a density (log_prob is None)")
-        if mfdist.is_active() and not hasattr(self.generator, "grad_reduce"):
-            raise NotImplementedError("data-parallel training is wired for the flow generators only")
         pieces = []
         for diagnostic, rows, meas, _, pre in groups:
             xt = apply_pre(x, pre)

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
                 for (int j = -RT; j <= RT; ++j) {
                     const int k = kc + j;
                     const int kk = min(max(k, 0), B - 1);
-                    const float r = (u - cl[kk]) * inv_sigma;
+                    const float r = (k == kk) ? (u - cl[kk]) * inv_sigma : 0.0f;   // masked too: u may be inf / NaN
                     const float g = (k == kk) ? img[q * B + kk] : 0.0f;
                     du = fmaf(g * gauss_weight(r), -r * inv_sigma, du);
                 }

@@ -206,3 +206,37 @@ def test_mentflow_loss_2d_nonlinear(backend):
     # the un-fused list API gives the same predictions
     preds = mf.simulate.forward(g["x"].to(backend), transforms, [[diag] for _ in transforms])
     assert len(preds) == 4 and all(len(p) == 1 and p[0].shape == (85,) for p in preds)
+
+
+def test_kde1d_backward_nonfinite_rows_same_in_both_window_variants(backend):
+    """the unrolled radius-4 backward window and the generic-radius loop must treat inf / NaN / far
+    out-of-range projections alike: such a particle touches no bin, its gradient row is exactly 0 — never NaN."""
+    torch.manual_seed(3)
+    n, d, P, B = 300, 3, 5, 32
+    x = torch.randn(n, d)
+    x[5, 0] = float("inf")
+    x[6, 1] = float("-inf")
+    x[7, 2] = float("nan")
+    x[8] = 1.0e30
+    x[9] = -3.0e38
+    V = torch.randn(P, d)
+    V = V / V.norm(dim=1, keepdim=True)
+    edges = torch.linspace(-4.0, 4.0, B + 1)
+    coords = 0.5 * (edges[1:] + edges[:-1])
+    delta = float(edges[1] - edges[0])
+    gS = torch.randn(P, B)
+    bad = [5, 6, 7, 8, 9]
+    outs = []
+    for bw_bins in (0.5, 0.5 + 1e-3):          # radius 4 (unrolled, RT = 4) and radius 5 (runtime-radius loop)
+        R = ops.kde_radius(bw_bins)
+        xs = x.to(backend).clone().requires_grad_(True)
+        S = ops.ProjKde1dFn.apply(xs, V.to(backend), coords.to(backend), bw_bins * delta, R)
+        (S * gS.to(backend)).sum().backward()
+        g = xs.grad.cpu()
+        assert torch.isfinite(g).all(), f"radius {R}: non-finite gradient rows {torch.nonzero(~torch.isfinite(g))[:4]}"
+        assert torch.equal(g[bad], torch.zeros(len(bad), d)), f"radius {R}: {g[bad]}"
+        outs.append((R, g))
+    assert outs[0][0] == 4 and outs[1][0] == 5
+    good = [i for i in range(n) if i not in bad]
+    # both variants agree on the ordinary rows (bandwidths differ by 0.2 %: loose tolerance, the point is no NaN leak)
+    torch.testing.assert_close(outs[0][1][good], outs[1][1][good], rtol=0.05, atol=0.05 * float(outs[0][1].abs().max()))
