@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 1
+#define MF_ABI_VERSION 2
 
 int mf_abi_version(void);
 const char* mf_last_error(void);
@@ -56,19 +56,32 @@ int mf_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, i
  *       skip the MFMA k-steps that only multiply masked-out (zero) weights — the image must then hold the hidden
  *       units sorted by dependency class as packing.py lays them out; NULL = dense products (any image).
  * bwd:  given gy[n,d] = dL/dy and glogp[n] = dL/dlogp, writes gx[n,d] = dL/dx (NULL for the first layer: the
- *       base draw needs no gradient) and accumulates dL/d(image) into gimage (same layout as image; must be
- *       zeroed by the caller before the first chunk).  `scratch` needs mf_flow_bwd_scratch_floats(n,...,order)
- *       floats: 0 when the call takes the fused kernel (parameter gradients inside the backward kernel: large
- *       batches with `order`), else (2 hidden_layers + d) * 64 floats per particle for the hand-off to the
- *       parameter-gradient kernel (callers then process the batch in chunks to bound it).                    */
+ *       base draw needs no gradient) and the parameter gradients dL/d(image) as PARTIAL SUMS, one per workgroup, into
+ *       the rows of gslab[slab_rows][mf_flow_image_floats] (image layout per row) with plain stores — no float
+ *       atomics, so the result is bitwise reproducible.  slab_rows must equal mf_flow_bwd_slab_rows(n, ...) (the
+ *       number of workgroup columns this call launches).  accumulate = 0: every row is overwritten (first chunk of a
+ *       backward pass: no zeroing needed); accumulate != 0: each workgroup adds to its own row (later chunks of the
+ *       same size class).  mf_flow_grad_reduce sums the rows in a fixed order into the flat parameter gradient.
+ *       `scratch` needs mf_flow_bwd_scratch_floats(n,...,order) floats: 0 when the call takes the fused kernel
+ *       (parameter gradients inside the backward kernel: large batches with `order`), else (2 hidden_layers + d) * 64
+ *       floats per particle for the hand-off to the parameter-gradient kernel (callers then process the batch in
+ *       chunks to bound it).                                                                                    */
 int64_t mf_flow_image_floats(int d, int hidden_layers);
 int64_t mf_flow_bwd_scratch_floats(int64_t n, int d, int hidden_layers, const int32_t* order);
 int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
                           const float* x, int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp,
                           void* stream);
+int mf_flow_bwd_slab_rows(int64_t n, int d, int hidden_layers, const int32_t* order);
 int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
-                          const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gimage,
-                          float* scratch, int64_t scratch_floats, void* stream);
+                          const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gslab,
+                          int slab_rows, int accumulate, float* scratch, int64_t scratch_floats, void* stream);
+
+/* Sum of the slab rows, all layers in one launch: gslab[layers][rows][image_floats] ->
+ * gflat[j] = sum_{r < rows} gslab[t][r][pos] with grad_index[j] = t * image_floats + pos (-1: parameter without an
+ * image slot -> 0).  Fixed summation order, fp64 accumulator: replaces the autograd accumulation of
+ * d(mask * W)/dW of zuko's MaskedLinear (reached from mentflow/generate/flows/zuko.py:24-26).                       */
+int mf_flow_grad_reduce(const float* gslab, int layers, int rows, int64_t image_floats, const int32_t* grad_index,
+                        float* gflat, int64_t numel, void* stream);
 
 /* Inverse of one layer, x = T^-1(y): the d autoregressive passes of zuko AutoregressiveTransform._inverse
  * (mentflow/generate/flows/zuko.py:21-22,31-32 -> log_prob / inverse of an arbitrary point).  `order` is required. */
@@ -82,9 +95,10 @@ int64_t mf_flow_affine_image_floats(int d, int hidden_layers);
 int64_t mf_flow_affine_bwd_scratch_floats(int64_t n, int hidden_layers);
 int mf_flow_affine_layer_fwd(const float* image, int d, int hidden_layers, const int32_t* order, const float* x,
                              int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp, void* stream);
+int mf_flow_affine_bwd_slab_rows(int64_t n);
 int mf_flow_affine_layer_bwd(const float* image, int d, int hidden_layers, const int32_t* order, const float* x,
-                             int64_t n, const float* gy, const float* glogp, float* gx, float* gimage, float* scratch,
-                             int64_t scratch_floats, void* stream);
+                             int64_t n, const float* gy, const float* glogp, float* gx, float* gslab, int slab_rows,
+                             int accumulate, float* scratch, int64_t scratch_floats, void* stream);
 int mf_flow_affine_layer_inv(const float* image, int d, int hidden_layers, const int32_t* order, const float* y,
                              int64_t n, float* x, void* stream);
 

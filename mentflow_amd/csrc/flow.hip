@@ -732,8 +732,8 @@ __device__ unsigned long long g_ws_diag[NUM_CU * 16];
 //     stage with a full 64 x 64 product : wave w owns block (w >> 1, w & 1), 4 tiles x 16 k-steps
 //     stage with one column tile        : wave w owns block (w & 1, 0) for tiles 2 (w >> 1) .. + 1  (k split)
 // so every wave keeps ONE accumulator block per stage (d last-layer blocks + L trunk levels: 9 x 16 registers for
-// d = 6, L = 3) for the whole kernel and adds it to gimage with float atomics at the end, exactly like
-// outer_accum_kernel.  Bias gradients are the row sums of S_A; the waves that share a row tile split the tiles.
+// d = 6, L = 3) for the whole kernel and stores it into the workgroup's slab row at the end (deterministic flush,
+// see dw_store), exactly like outer_accum_kernel.  Bias gradients are the row sums of S_A; the waves that share a row tile split the tiles.
 // Staged element (row, particle p) lives at row*32 + (((p >> 2) ^ (row >> 1)) & 7) * 4 + (p & 3): the 16-byte chunks
 // of a row are XOR-swizzled by row/2 so that both the producers' scalar writes (32 particles of one row, 32 banks) and the
 // consumers' ds_read_b128 (4 particles of one row per lane; 64 banks, 16-lane groups {0-3,12-15,20-27}, ...: the eight
@@ -826,17 +826,54 @@ __device__ __forceinline__ void dw_accum(const float* SA, const float* SB, int r
     }
 }
 
-// gW[(32 ra + row) * stride + 32 rb + col] += acc   (columns < ncols only)
-__device__ __forceinline__ void dw_flush(float* gW, int stride, int ncols, int ra, int rb, int lane, const f32x16_t& acc) {
+// ---- deterministic flush of the per-workgroup parameter-gradient accumulators -------------------------------------
+// Every workgroup owns one ROW of a slab buffer gslab[rows][image floats] and writes its accumulator blocks there with
+// plain coalesced stores (accumulate != 0: read-modify-write of its own row — later chunks of one backward pass);
+// mf_flow_grad_reduce then sums the rows in a fixed order (fp64 accumulation).  No float atomics: the parameter
+// gradients are bitwise reproducible run to run, and nothing contends at the end of the kernel.
+// gW[(32 ra + row) * stride + 32 rb + col] (+)= acc   (columns < ncols only)
+__device__ __forceinline__ void dw_store(float* gW, int stride, int ncols, int ra, int rb, int lane, const f32x16_t& acc,
+                                         int accumulate) {
     const int j = lane & 31, hh = lane >> 5;
     if (32 * rb + j < ncols) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(&gW[(32 * ra + rowmap(r, hh)) * stride + 32 * rb + j], acc[r]);
+        for (int r = 0; r < 16; ++r) {
+            float* q = &gW[(32 * ra + rowmap(r, hh)) * stride + 32 * rb + j];
+            *q = accumulate ? *q + acc[r] : acc[r];
+        }
     }
 }
-__device__ __forceinline__ void bias_flush(float* gB, int ra, int lane, float bsum) {
+// bsum: per-lane partial row sums (row = lane & 31, the two lane halves hold the two k-halves)
+__device__ __forceinline__ void bias_store(float* gB, int ra, int lane, float bsum, int accumulate) {
     bsum += __shfl_xor(bsum, 32);
-    if (lane < 32) atomicAdd(&gB[32 * ra + lane], bsum);
+    if (lane < 32) gB[32 * ra + lane] = accumulate ? gB[32 * ra + lane] + bsum : bsum;
+}
+// Two waves that split the k range (tile pairs) of ONE output block — waves w and w ^ 2 — meet in LDS: on return the
+// accumulators of waves 0 / 1 hold the sum (fixed order: low wave + high wave).  X: 2 * FB_XCH floats, free at kernel end.
+constexpr int FB_XCH = 16 * 64 + 64;
+__device__ __forceinline__ void pair_reduce_k(float* X, int wid, int lane, f32x16_t& acc, float& bsum) {
+    __syncthreads();
+    if (wid >= 2) {
+        float* q = X + (wid - 2) * FB_XCH;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[r * 64 + lane] = acc[r];
+        q[1024 + lane] = bsum;
+    }
+    __syncthreads();
+    if (wid < 2) {
+        const float* q = X + wid * FB_XCH;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += q[r * 64 + lane];
+        bsum += q[1024 + lane];
+    }
+}
+// The two waves that share a ROW tile of a full 64 x 64 product (waves 2 ra and 2 ra + 1) split its bias row sums:
+// the even wave ends up with the total.
+__device__ __forceinline__ void pair_reduce_bias(float* X, int wid, int lane, float& bsum) {
+    __syncthreads();
+    if (wid & 1) X[(wid >> 1) * 64 + lane] = bsum;
+    __syncthreads();
+    if (!(wid & 1)) bsum += X[(wid >> 1) * 64 + lane];
 }
 
 template <int K, int L>
@@ -844,10 +881,11 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                                                                         const float* __restrict__ x, int64_t n,
                                                                         const float* __restrict__ gy,
                                                                         const float* __restrict__ glogp,
-                                                                        float* __restrict__ gx, float* __restrict__ gimage,
-                                                                        Sparsity sp) {
+                                                                        float* __restrict__ gx, float* __restrict__ gslab,
+                                                                        int accumulate, Sparsity sp) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
+    float* gimage = gslab + (int64_t)blockIdx.x * g.total;     // this workgroup's slab row
     // ---- stage the image: trunk as is; last-layer block i TRANSPOSED and compacted to the hidden columns its mask
     // leaves non-zero: T_i[c][m] = W3_i[m][c], c < ncols_i, row stride WS.  Both products then walk LDS with immediate
     // offsets: phi = W3 h reads column m of T (stride WS), gh += W3^T gphi reads row c of T (contiguous).
@@ -1112,24 +1150,36 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         WS_ACC(c_[11], tl_);
     }
     t0_ = WS_T();
-    // ---- flush the accumulators (image coordinates)
+    // ---- flush the accumulators (image coordinates) into this workgroup's slab row: plain stores, fixed order
 #pragma unroll
     for (int i = 0; i < FB_DMAX; ++i) {
         if (i < d) {
             const bool full = sp.rt1[i] != 0;
-            const int ra = full ? fra : hra, rb = full ? frb : 0;
-            if (sp.kend3[i] > 0) dw_flush(gimage + g.offW3 + i * HID * WS, WS, HID, ra, rb, lane, accO[i]);
-            bias_flush(gimage + g.offB3 + i * HID, ra, lane, bsO[i]);
+            if (full) {
+                pair_reduce_bias(SA, wid, lane, bsO[i]);
+                if (sp.kend3[i] > 0) dw_store(gimage + g.offW3 + i * HID * WS, WS, HID, fra, frb, lane, accO[i], accumulate);
+                if (frb == 0) bias_store(gimage + g.offB3 + i * HID, fra, lane, bsO[i], accumulate);
+            } else {
+                pair_reduce_k(SA, wid, lane, accO[i], bsO[i]);
+                if (wid < 2) {
+                    if (sp.kend3[i] > 0) dw_store(gimage + g.offW3 + i * HID * WS, WS, HID, hra, 0, lane, accO[i], accumulate);
+                    bias_store(gimage + g.offB3 + i * HID, hra, lane, bsO[i], accumulate);
+                }
+            }
         }
     }
 #pragma unroll
     for (int l = 1; l < L; ++l) {
         float* gW = gimage + g.offWh + (l - 1) * (HID * WS + HID);
-        if (!(fra == 0 && frb == 1 && sp.kend_h[0] <= 16)) dw_flush(gW, WS, HID, fra, frb, lane, accT[l]);
-        bias_flush(gW + HID * WS, fra, lane, bsT[l]);
+        pair_reduce_bias(SA, wid, lane, bsT[l]);
+        if (!(fra == 0 && frb == 1 && sp.kend_h[0] <= 16)) dw_store(gW, WS, HID, fra, frb, lane, accT[l], accumulate);
+        if (frb == 0) bias_store(gW + HID * WS, fra, lane, bsT[l], accumulate);
     }
-    dw_flush(gimage + g.offW0, g.S0, d, hra, 0, lane, accT[0]);
-    bias_flush(gimage + g.offB0, hra, lane, bsT[0]);
+    pair_reduce_k(SA, wid, lane, accT[0], bsT[0]);
+    if (wid < 2) {
+        dw_store(gimage + g.offW0, g.S0, d, hra, 0, lane, accT[0], accumulate);
+        bias_store(gimage + g.offB0, hra, lane, bsT[0], accumulate);
+    }
 #if defined(MF_WS_DIAG) && !defined(MF_EMU)
     __builtin_amdgcn_s_waitcnt(0);
     c_[7] = WS_T() - t0_;                                  // slot 7: the final flush, once per workgroup
@@ -1400,13 +1450,14 @@ __global__ __launch_bounds__(FLOW_BLOCK) void affine_layer_bwd_kernel(const floa
 // layer of the conditioner.  grid (G, 2): blockIdx.y = 0 -> the `nblk` output blocks of the last layer (wave w owns
 // block w: A = GPHI[w], B = ACT[L-1] shared by all waves of the workgroup through L1/L2);  blockIdx.y = 1 -> the trunk
 // (wave 0: A = GPRE[0], B = x;  wave l: A = GPRE[l], B = ACT[l-1]).  Every wave keeps its 64x64 result in 64
-// accumulator registers over all the tiles it visits and adds it to gimage (image coordinates) with float atomics.
+// accumulator registers over all the tiles it visits and stores it into its slab row (image coordinates, see dw_store).
 constexpr int OA_MAX_WAVES = 8;
 __global__ __launch_bounds__(64 * OA_MAX_WAVES) void outer_accum_kernel(const float* __restrict__ scratch,
                                                                         const float* __restrict__ x, int64_t n, int d,
-                                                                        int L, int nblk, float* __restrict__ gimage,
-                                                                        Sparsity sp) {
+                                                                        int L, int nblk, float* __restrict__ gslab,
+                                                                        int accumulate, Sparsity sp) {
     const ImageLayout g = image_layout(d, L, nblk);
+    float* gimage = gslab + (int64_t)blockIdx.x * g.total;     // this workgroup column's slab row (blockIdx.y: disjoint parts)
     const int64_t ntiles = (n + 31) / 32;
     const int64_t npad = ntiles * 32;
     const float* ACT = scratch;
@@ -1514,15 +1565,16 @@ __global__ __launch_bounds__(64 * OA_MAX_WAVES) void outer_accum_kernel(const fl
             for (int r = 0; r < 16; ++r) {
                 const int wA = rowmap(r, hh);                       // C row within the tile = memory column of A
                 const int rhoA = 32 * ta + rowmap(wA & 15, wA >> 4);
-                atomicAdd(&gimage[offW + rhoA * strideW + rhoB], acc[ta][tb][r]);
+                float* q = &gimage[offW + rhoA * strideW + rhoB];
+                *q = accumulate ? *q + acc[ta][tb][r] : acc[ta][tb][r];
             }
         }
     bsum0 += __shfl_xor(bsum0, 32);
     bsum1 += __shfl_xor(bsum1, 32);
     if (hh == 0) {
         const int rho = rowmap(col & 15, col >> 4);
-        atomicAdd(&gimage[offB + rho], bsum0);
-        atomicAdd(&gimage[offB + 32 + rho], bsum1);
+        gimage[offB + rho] = accumulate ? gimage[offB + rho] + bsum0 : bsum0;
+        gimage[offB + 32 + rho] = accumulate ? gimage[offB + 32 + rho] + bsum1 : bsum1;
     }
 }
 
@@ -1536,9 +1588,11 @@ __global__ __launch_bounds__(FB_BLOCK) void affine_layer_bwd_fused_kernel(const 
                                                                            const float* __restrict__ x, int64_t n,
                                                                            const float* __restrict__ gy,
                                                                            const float* __restrict__ glogp,
-                                                                           float* __restrict__ gx, float* __restrict__ gimage) {
+                                                                           float* __restrict__ gx, float* __restrict__ gslab,
+                                                                           int accumulate) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, 1);
+    float* gimage = gslab + (int64_t)blockIdx.x * g.total;     // this workgroup's slab row
     stage_image<FB_BLOCK>(lds, image, g.total);
     float* SA = lds + ((g.total + 3) & ~3);
     float* SB = SA + 4 * FB_TILE;
@@ -1699,16 +1753,24 @@ __global__ __launch_bounds__(FB_BLOCK) void affine_layer_bwd_fused_kernel(const 
             }
         }
     }
-    dw_flush(gimage + g.offW3, WS, HID, 0, frb, lane, accO);
-    if (frb == 0) bias_flush(gimage + g.offB3, 0, lane, bsO);
+    // ---- deterministic flush into this workgroup's slab row (see dw_store)
+    pair_reduce_k(SA, wid, lane, accO, bsO);               // block (0, frb): k split over waves w, w ^ 2; bias in wave 0
+    if (wid < 2) {
+        dw_store(gimage + g.offW3, WS, HID, 0, frb, lane, accO, accumulate);
+        if (frb == 0) bias_store(gimage + g.offB3, 0, lane, bsO, accumulate);
+    }
 #pragma unroll
     for (int l = 1; l < L; ++l) {
         float* gW = gimage + g.offWh + (l - 1) * (HID * WS + HID);
-        dw_flush(gW, WS, HID, fra, frb, lane, accT[l]);
-        bias_flush(gW + HID * WS, fra, lane, bsT[l]);
+        pair_reduce_bias(SA, wid, lane, bsT[l]);
+        dw_store(gW, WS, HID, fra, frb, lane, accT[l], accumulate);
+        if (frb == 0) bias_store(gW + HID * WS, fra, lane, bsT[l], accumulate);
     }
-    dw_flush(gimage + g.offW0, g.S0, d, hra, 0, lane, accT[0]);
-    bias_flush(gimage + g.offB0, hra, lane, bsT[0]);
+    pair_reduce_k(SA, wid, lane, accT[0], bsT[0]);
+    if (wid < 2) {
+        dw_store(gimage + g.offW0, g.S0, d, hra, 0, lane, accT[0], accumulate);
+        bias_store(gimage + g.offB0, hra, lane, bsT[0], accumulate);
+    }
 }
 
 static int flow_check(int d, int L, int64_t n) {
@@ -1791,13 +1853,40 @@ extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layer
                 hidden_layers);
 }
 
+// grid sizes of the backward kernels: the number of slab rows a call writes (one per workgroup column)
+static int fused_grid(int64_t n) {
+    const int64_t ngroups = ((n + 31) / 32 + 3) / 4;
+    return (int)(ngroups > NUM_CU ? NUM_CU : (ngroups < 1 ? 1 : ngroups));
+}
+static int outer_accum_grid(int64_t n) {
+    static const int oa_mult = [] { const char* e = getenv("MENTFLOW_OA_MULT"); return e ? atoi(e) : 2; }();
+    const int64_t ntiles = (n + 31) / 32;
+    int64_t G = (ntiles + 7) / 8;                    // at least 8 tiles of work per workgroup
+    if (G > oa_mult * NUM_CU) G = oa_mult * NUM_CU;
+    if (G < 1) G = 1;
+    return (int)G;
+}
+
+extern "C" int mf_flow_bwd_slab_rows(int64_t n, int d, int hidden_layers, const int32_t* order) {
+    if (n <= 0) return 0;
+    if (order != nullptr && d >= 1 && d <= FLOW_DMAX) {
+        size_t smem;
+        if (rqs_bwd_fused(n, d, hidden_layers, order, make_sparsity(d, order, d), &smem)) return fused_grid(n);
+    }
+    return outer_accum_grid(n);
+}
+
 extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
                                       const float* x, int64_t n, const float* gy, const float* glogp, float* gx,
-                                      float* gimage, float* scratch, int64_t scratch_floats, void* stream) {
+                                      float* gslab, int slab_rows, int accumulate, float* scratch, int64_t scratch_floats,
+                                      void* stream) {
     if (flow_check(d, hidden_layers, n)) return 1;
     if (n == 0) return 0;
     const Sparsity sp = make_sparsity(d, order, d);
     if (scratch_floats < mf_flow_bwd_scratch_floats(n, d, hidden_layers, order)) return fail("scratch too small");
+    if (slab_rows != mf_flow_bwd_slab_rows(n, d, hidden_layers, order))
+        return fail("gslab has %d rows, this call writes %d (mf_flow_bwd_slab_rows)", slab_rows,
+                    mf_flow_bwd_slab_rows(n, d, hidden_layers, order));
     const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, d).total;
     bool launched = false;
     // fused backward + parameter gradients (no scratch traffic): 19.2 ms against 11.1 + 9.3 ms at 2 M particles (C4)
@@ -1805,14 +1894,13 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
         size_t smem_f = 0;
         if (!launched && rqs_bwd_fused(n, d, hidden_layers, order, sp, &smem_f)) {
             {
-                const int64_t ngroups = ((n + 31) / 32 + 3) / 4;
-                const int gf = (int)(ngroups > NUM_CU ? NUM_CU : ngroups);
+                const int gf = fused_grid(n);
 #define XF(KK, LL)                                                                                                    \
     if (!launched && bins == KK && hidden_layers == LL) {                                                             \
         ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
         MF_ALLOW_DYN_SMEM((rqs_layer_bwd_fused_kernel<KK, LL>), smem_f);                                              \
         MF_LAUNCH((rqs_layer_bwd_fused_kernel<KK, LL>), gf, FB_BLOCK, smem_f, stream, image, d, x, n, gy, glogp, gx,   \
-                  gimage, sp);                                                                                           \
+                  gslab, accumulate, sp);                                                                                \
         launched = true;                                                                                              \
     }
                 MF_RQS_CASES(XF)
@@ -1847,17 +1935,11 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
         return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: bins in {8,20}, hidden_layers in {2,3})",
                     bins, hidden_layers);
     if (check_launch("mf_flow_rqs_layer_bwd")) return 1;
-    const int64_t ntiles = (n + 31) / 32;
-    static const int oa_mult = [] { const char* e = getenv("MENTFLOW_OA_MULT"); return e ? atoi(e) : 2; }();
-    // every workgroup ends with a 4096-atomics-per-wave flush of its accumulators: give it at least 8 tiles of work
-    int64_t G = (ntiles + 7) / 8;
-    if (G > oa_mult * NUM_CU) G = oa_mult * NUM_CU;
-    if (G < 1) G = 1;
     const int nwaves = d > hidden_layers ? d : hidden_layers;
     if (nwaves > OA_MAX_WAVES) return fail("too many linear blocks for the gradient kernel");
     ProfScope prof(PK_OUTER_ACCUM, stream);
-    MF_LAUNCH(outer_accum_kernel, dim3((unsigned)G, 2), 64 * nwaves, 0, stream, (const float*)scratch, x, n, d,
-              hidden_layers, d, gimage, sp);
+    MF_LAUNCH(outer_accum_kernel, dim3((unsigned)outer_accum_grid(n), 2), 64 * nwaves, 0, stream, (const float*)scratch, x, n,
+              d, hidden_layers, d, gslab, accumulate, sp);
     return check_launch("mf_flow_rqs_layer_bwd(outer_accum)");
 }
 
@@ -1900,25 +1982,32 @@ extern "C" int mf_flow_affine_layer_fwd(const float* image, int d, int hidden_la
     return fail("no affine kernel instance for hidden_layers=%d (built: 2, 3)", hidden_layers);
 }
 
+extern "C" int mf_flow_affine_bwd_slab_rows(int64_t n) {
+    if (n <= 0) return 0;
+    return affine_bwd_fused(n) ? fused_grid(n) : outer_accum_grid(n);
+}
+
 extern "C" int mf_flow_affine_layer_bwd(const float* image, int d, int hidden_layers, const int32_t* order, const float* x,
-                                         int64_t n, const float* gy, const float* glogp, float* gx, float* gimage,
-                                         float* scratch, int64_t scratch_floats, void* stream) {
+                                         int64_t n, const float* gy, const float* glogp, float* gx, float* gslab,
+                                         int slab_rows, int accumulate, float* scratch, int64_t scratch_floats, void* stream) {
     if (flow_check(d, hidden_layers, n)) return 1;
     if (n == 0) return 0;
     if (scratch_floats < mf_flow_affine_bwd_scratch_floats(n, hidden_layers)) return fail("scratch too small");
+    if (slab_rows != mf_flow_affine_bwd_slab_rows(n))
+        return fail("gslab has %d rows, this call writes %d (mf_flow_affine_bwd_slab_rows)", slab_rows,
+                    mf_flow_affine_bwd_slab_rows(n));
     const Sparsity sp = make_sparsity(d, order, 1);
     const size_t smem = sizeof(float) * (size_t)image_layout(d, hidden_layers, 1).total;
     bool launched = false;
     if (affine_bwd_fused(n)) {
         const size_t smem_f = sizeof(float) * ((((size_t)image_layout(d, hidden_layers, 1).total + 3) & ~(size_t)3) + 8 * (size_t)FB_TILE);
-        const int64_t ngroups = ((n + 31) / 32 + 3) / 4;
-        const int gf = (int)(ngroups > NUM_CU ? NUM_CU : ngroups);
+        const int gf = fused_grid(n);
 #define XF(LL)                                                                                                        \
     if (!launched && hidden_layers == LL) {                                                                           \
         ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
         MF_ALLOW_DYN_SMEM((affine_layer_bwd_fused_kernel<LL>), smem_f);                                               \
         MF_LAUNCH((affine_layer_bwd_fused_kernel<LL>), gf, FB_BLOCK, smem_f, stream, image, d, x, n, gy, glogp, gx,    \
-                  gimage);                                                                                            \
+                  gslab, accumulate);                                                                                 \
         launched = true;                                                                                              \
     }
         MF_AFFINE_CASES(XF)
@@ -1938,14 +2027,49 @@ extern "C" int mf_flow_affine_layer_bwd(const float* image, int d, int hidden_la
 #undef X
     if (!launched) return fail("no affine kernel instance for hidden_layers=%d (built: 2, 3)", hidden_layers);
     if (check_launch("mf_flow_affine_layer_bwd")) return 1;
-    const int64_t ntiles = (n + 31) / 32;
-    int64_t G = (ntiles + 7) / 8;
-    if (G > 2 * NUM_CU) G = 2 * NUM_CU;
-    if (G < 1) G = 1;
     ProfScope prof(PK_OUTER_ACCUM, stream);
-    MF_LAUNCH(outer_accum_kernel, dim3((unsigned)G, 2), 64 * hidden_layers, 0, stream, (const float*)scratch, x, n, d,
-              hidden_layers, 1, gimage, sp);
+    MF_LAUNCH(outer_accum_kernel, dim3((unsigned)outer_accum_grid(n), 2), 64 * hidden_layers, 0, stream, (const float*)scratch,
+              x, n, d, hidden_layers, 1, gslab, accumulate, sp);
     return check_launch("mf_flow_affine_layer_bwd(outer_accum)");
+}
+
+// ------------------------------------------------------------------------------------------------ gradient reduce
+// gflat[j] = sum over the slab rows r = 0 .. rows-1 (fixed order, fp64 accumulation) of gslab[t][r][pos], where
+// grad_index[j] = t * image_floats + pos (or -1: masked-out / padding parameter -> 0).  One launch for all T layers.
+namespace mf {
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ gslab, int rows, int64_t image_floats,
+                                                          const int32_t* __restrict__ grad_index, float* __restrict__ gflat,
+                                                          int64_t numel) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= numel) return;
+    const int32_t idx = grad_index[j];
+    if (idx < 0) {
+        gflat[j] = 0.0f;
+        return;
+    }
+    const int64_t t = idx / image_floats, pos = idx - t * image_floats;
+    const float* p = gslab + (t * rows) * image_floats + pos;
+    double acc = 0.0;
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(r + u) * image_floats];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; r < rows; ++r) acc += (double)p[(int64_t)r * image_floats];
+    gflat[j] = (float)acc;
+}
+}  // namespace mf
+
+extern "C" int mf_flow_grad_reduce(const float* gslab, int layers, int rows, int64_t image_floats, const int32_t* grad_index,
+                                    float* gflat, int64_t numel, void* stream) {
+    if (layers < 1 || rows < 1 || image_floats < 1 || numel < 0) return fail("bad arguments to mf_flow_grad_reduce");
+    if (numel == 0) return 0;
+    MF_LAUNCH(grad_reduce_kernel, (unsigned)((numel + 255) / 256), 256, 0, stream, gslab, rows, image_floats, grad_index, gflat,
+              numel);
+    return check_launch("mf_flow_grad_reduce");
 }
 
 // ------------------------------------------------------------------------------------------------ inverse C ABI

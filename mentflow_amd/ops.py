@@ -57,15 +57,44 @@ def _layer_fwd(spec: FlowSpec, t: int, image: torch.Tensor, x: torch.Tensor, y: 
              ptr(logp_out), int(init), stream_ptr(x))
 
 
-def _layer_bwd(spec: FlowSpec, t: int, image, x, gy, glogp, gx, gimage, scratch) -> None:
+def _layer_bwd(spec: FlowSpec, t: int, image, x, gy, glogp, gx, gslab, accumulate: bool, scratch) -> None:
     n = x.shape[0]
     order = spec.orders[t] if spec.sparse else None
+    rows = gslab.shape[0]
     if spec.kind == "rqs":
         call("mf_flow_rqs_layer_bwd", ptr(image), spec.d, spec.L, spec.bins, order, ptr(x), n, ptr(gy), ptr(glogp),
-             ptr(gx), ptr(gimage), ptr(scratch), scratch.numel(), stream_ptr(x))
+             ptr(gx), ptr(gslab), rows, int(accumulate), ptr(scratch), scratch.numel(), stream_ptr(x))
     else:
         call("mf_flow_affine_layer_bwd", ptr(image), spec.d, spec.L, order, ptr(x), n, ptr(gy), ptr(glogp), ptr(gx),
-             ptr(gimage), ptr(scratch), scratch.numel(), stream_ptr(x))
+             ptr(gslab), rows, int(accumulate), ptr(scratch), scratch.numel(), stream_ptr(x))
+
+
+def _bwd_plan(spec: FlowSpec, n: int):
+    """(chunk, scratch_floats, slab_rows) of a backward pass over n particles: the fused kernels need no scratch and
+    take the whole batch in one launch per layer; the two-kernel path is chunked to bound its hand-off scratch.  Every
+    chunk of a pass must write the same number of slab rows (each workgroup accumulates into its own row), so a ragged
+    last chunk is only allowed when it does."""
+    lib = _lib.get_lib()
+    if spec.kind == "rqs":
+        orders = spec.orders if spec.sparse else [None]
+
+        def need(m):
+            return max(lib.mf_flow_bwd_scratch_floats(m, spec.d, spec.L, o) for o in orders)
+
+        def rows(m):
+            r = {lib.mf_flow_bwd_slab_rows(m, spec.d, spec.L, o) for o in orders}
+            if len(r) != 1:
+                raise RuntimeError("layers of one flow disagree on the backward variant")
+            return r.pop()
+    else:
+        def need(m):
+            return lib.mf_flow_affine_bwd_scratch_floats(m, spec.L)
+
+        def rows(m):
+            return lib.mf_flow_affine_bwd_slab_rows(m)
+
+    chunk = n if need(n) == 0 else min(n, spec.bwd_chunk)
+    return chunk, need(chunk), rows
 
 
 def pack_images(spec: FlowSpec, flat: torch.Tensor) -> torch.Tensor:
@@ -108,35 +137,28 @@ class FlowSampleFn(torch.autograd.Function):
         dev = images.device
         gx = torch.zeros(n, spec.d, dtype=_F32, device=dev) if gx is None else _f32c(gx)
         glogp = torch.zeros(n, dtype=_F32, device=dev) if glogp is None else _f32c(glogp)
-        gimages = torch.zeros_like(images)
-        chunk = min(n, spec.bwd_chunk)
-        if spec.kind == "rqs":
-            lib = _lib.get_lib()
-            orders = spec.orders if spec.sparse else [None]
-
-            def need(m):
-                return max(lib.mf_flow_bwd_scratch_floats(m, spec.d, spec.L, o) for o in orders)
-
-            if need(n) == 0:
-                chunk = n                       # fused backward: no hand-off scratch, one launch per layer
-            scratch_floats = need(chunk)
-        else:
-            lib = _lib.get_lib()
-            if lib.mf_flow_affine_bwd_scratch_floats(n, spec.L) == 0:
-                chunk = n                       # fused backward: no hand-off scratch
-            scratch_floats = lib.mf_flow_affine_bwd_scratch_floats(chunk, spec.L)
+        chunk, scratch_floats, rows_of = _bwd_plan(spec, n)
         scratch = torch.empty(max(scratch_floats, 1), dtype=_F32, device=dev)
+        # chunks grouped by the number of slab rows they write (at most two groups: full chunks and a ragged last one)
+        spans = [(a, min(n, a + chunk)) for a in range(0, n, chunk)]
+        groups = {}
+        for a, b in spans:
+            groups.setdefault(rows_of(b - a), []).append((a, b))
+        gflat = None
         g = gx
+        slabs = {r: torch.empty(spec.T, r, spec.image_floats, dtype=_F32, device=dev) for r in groups}
         for t in reversed(range(spec.T)):
             gprev = torch.empty_like(g) if t > 0 else None
-            for a in range(0, n, chunk):
-                b = min(n, a + chunk)
-                _layer_bwd(spec, t, images[t], xs[t][a:b], g[a:b], glogp[a:b], None if gprev is None else gprev[a:b],
-                           gimages[t], scratch)
+            for r, members in groups.items():
+                for k, (a, b) in enumerate(members):
+                    _layer_bwd(spec, t, images[t], xs[t][a:b], g[a:b], glogp[a:b], None if gprev is None else gprev[a:b],
+                               slabs[r][t], k > 0, scratch)
             g = gprev
-        gflat = torch.empty(spec.grad_index.numel(), dtype=_F32, device=dev)
-        call("mf_gather_f32", ptr(gimages.view(-1)), ptr(spec.grad_index), ptr(gflat), gflat.numel(), 0,
-             stream_ptr(gflat))
+        for r, slab in slabs.items():
+            part = torch.empty(spec.grad_index.numel(), dtype=_F32, device=dev)
+            call("mf_flow_grad_reduce", ptr(slab), spec.T, r, spec.image_floats, ptr(spec.grad_index), ptr(part),
+                 part.numel(), stream_ptr(part))
+            gflat = part if gflat is None else gflat + part
         if ctx.grad_reduce is not None:
             ctx.grad_reduce(gflat)
         return None, gflat, None, None

@@ -5,6 +5,7 @@ set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r02a
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
+./tools/bin/ubench_lds_atomics2 > $OUT/ubench_lds_atomics2.txt 2>&1 || echo "ubench failed"
 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1 || { tail -30 $OUT/pytest_gpu.txt; exit 1; }
 tail -3 $OUT/pytest_gpu.txt
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err && echo "bench default done" &&
