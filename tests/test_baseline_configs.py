@@ -17,7 +17,9 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def _check(prob, n, dev, dtype=torch.float32, gtol=2e-3):
+def _check(prob, n, dev, dtype=torch.float32, gtol=5e-4):
+    """Gates at ~3x the achieved error on the default initialisation (bench parity gate: gradients 1.4e-4 of the largest
+    entry, |dL| 2e-6): H 2e-5 rel, D 2e-4 rel, L 1e-4 + mu 2e-6, parameter gradients 5e-4 of the largest entry."""
     torch.manual_seed(123)
     d = prob.cfg["ndim"]
     z = torch.randn(n, d)
@@ -31,7 +33,8 @@ def _check(prob, n, dev, dtype=torch.float32, gtol=2e-3):
     assert abs(float(H.detach()) - float(Ho)) < 2e-5 * max(1.0, abs(float(Ho)))
     assert (Dk - Dr).abs().max() < 2e-6 + 2e-4 * float(Dr.abs().max())
     assert abs(float(L.detach()) - float(Lo)) < 1e-4 + mu * 2e-6 + 1e-5 * abs(float(Lo))
-    assert (g.double() - go.double()).abs().max() < gtol * float(go.abs().max())
+    eg = float((g.double() - go.double()).abs().max() / go.abs().max())
+    assert eg < gtol, f"parameter-gradient error {eg:.2e} of the largest entry (gate {gtol:.0e})"
     return float(L.detach()), float(Lo)
 
 
@@ -65,4 +68,14 @@ def test_c5_shape_2d_projections(dev):
     prob = build_problem(ndim=6, num=12, bins=85, xmax=3.5, seed=0, transforms=5, prior_scale=3.0, device=dev,
                          dist_name="gaussian_mixture", optics="nd_2d_random", meas_samples=200_000,
                          penalty_parameter=500.0)
+    _check(prob, 2_048, dev)
+
+
+def test_c5_all_100_2d_projections(dev):
+    """C5 as BASELINE.json states it: ONE HUNDRED 2-D projections x 85 x 85 bins (every projection group of the 2-D
+    kernels, the full measurement stack), oracle-sized batch."""
+    prob = build_problem(ndim=6, num=100, bins=85, xmax=3.5, seed=0, transforms=5, prior_scale=3.0, device=dev,
+                         dist_name="gaussian_mixture", optics="nd_2d_random", meas_samples=200_000,
+                         penalty_parameter=500.0)
+    assert len(prob.transforms) == 100
     _check(prob, 2_048, dev)

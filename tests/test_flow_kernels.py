@@ -1,8 +1,13 @@
 """Flow kernels (through the C ABI + mentflow-compatible generator API) against the oracle restatement
 (oracle/flow.py — parity unpinned, see its header) on identical weights and injected base draws z.
 
-fp32 tolerances: x atol 5e-5, log_prob atol 5e-4 (deliberately steep splines, |ladj| ~ 10), parameter gradients
-2e-3 of the largest gradient entry; the oracle is evaluated in fp64 where stated so that both fp32 sides are judged
+fp32 tolerances.  On the DEFAULT initialisation (what the benchmark and the reference train from) the gates are the
+contract of SURVEY.md §8(d) at ~3x the achieved error: x atol 1e-5, log_prob atol 1e-4, parameter gradients 5e-4 of
+the largest entry (test_nsf_default_init_tight_gates).  The "steep" cases scale the last conditioner layer by 4 and
+randomise its bias so that every spline bin and the identity tails are exercised with |ladj| ~ 10 and knot slopes
+down to 1e-3: fp32 rounding of x is amplified by those slopes in BOTH fp32 implementations (kernel and fp32 oracle),
+so their gates are wider — x 5e-5, log_prob 5e-4, gradients 2e-3 of the largest entry — and the fp32 oracle is held to
+the same band against the fp64 one.  The oracle is evaluated in fp64 where stated so that both fp32 sides are judged
 against a common, more accurate value."""
 import pytest
 import torch
@@ -71,13 +76,42 @@ def test_nsf_backward_matches_oracle(backend, d, variant, monkeypatch):
     xo, lo = of.sample_and_log_prob(z.double(), s64)
     ((xo * wx.double()).sum() + (lo * wl.double()).sum()).backward()
     go = torch.cat([p.grad.reshape(-1) for p in ps])
-    assert (gk.double() - go).abs().max() < 2e-3 * go.abs().max()
+    err = float((gk.double() - go).abs().max() / go.abs().max())
+    assert err < 2e-3, f"steep-weights case (slopes to 1e-3 amplify fp32 rounding): gradient error {err:.2e} of max"
     # masked-out weights get exactly zero gradient (d(mask*W)/dW = mask)
     off = 0
     for layer in gen.layers:
         for lin in layer.linears():
             gw = lin.weight.grad.cpu()
             assert (gw[~lin.mask.cpu()] == 0).all()
+
+
+@pytest.mark.parametrize("variant", ["two-kernel", "fused"])
+@pytest.mark.parametrize("d", [6, 2])
+def test_nsf_default_init_tight_gates(backend, d, variant, monkeypatch):
+    """SURVEY.md §8(d) gates on default-initialised weights (the timed model): x 1e-5, log_prob 1e-4, parameter
+    gradients 5e-4 of the largest entry (~3x the error the bench parity gate reports), both backward variants."""
+    monkeypatch.setenv("MENTFLOW_BWD_FUSED", "1" if variant == "fused" else "0")
+    gen = make_generator(backend, d, transforms=5, steep=False)
+    torch.manual_seed(12)
+    n = 70 if variant == "two-kernel" else 300
+    z = torch.randn(n, d)
+    wx, wl = torch.randn(n, d), torch.randn(n)
+    x, lp = gen.sample_and_log_prob(n, z=z.to(backend))
+    ((x * wx.to(backend)).sum() + (lp * wl.to(backend)).sum()).backward()
+    gk = torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).cpu()
+    s64 = flow_spec_from_generator(gen, torch.float64)
+    ps = s64.parameters()
+    for p in ps:
+        p.requires_grad_(True)
+    xo, lo = of.sample_and_log_prob(z.double(), s64)
+    ((xo * wx.double()).sum() + (lo * wl.double()).sum()).backward()
+    go = torch.cat([p.grad.reshape(-1) for p in ps])
+    ex, el = float((x.detach().cpu() - xo).abs().max()), float((lp.detach().cpu() - lo).abs().max())
+    eg = float((gk.double() - go).abs().max() / go.abs().max())
+    assert ex < 1e-5, f"x error {ex:.2e}"
+    assert el < 1e-4, f"log_prob error {el:.2e}"
+    assert eg < 5e-4, f"parameter-gradient error {eg:.2e} of the largest entry"
 
 
 def test_default_init_is_near_identity_and_state_dict_keys(backend):

@@ -117,3 +117,86 @@ def test_c5_2d_histograms_additive(dev):
     ratio = S.sum(2)[inside] / S1[inside].clamp_min(1e-3)
     big = S1[inside] > 100.0
     assert ((ratio[big] - 1.2533).abs() < 5e-3).all()
+
+
+def test_c2_full_size_flow_and_histograms(dev, monkeypatch):
+    """C2 at its full size: d = 2 NSF 5 x [3 x 64] K = 20, 7 rotations x 85 bins, 1 048 576 particles."""
+    prob = build_problem(ndim=2, num=7, bins=85, xmax=3.5, seed=21, transforms=5, prior_scale=1.0, device=dev,
+                         dist_name="swissroll", optics="2d_linear", gen_name="nsf", meas_samples=200_000,
+                         penalty_parameter=500.0)
+    gen = prob.model.generator
+    n = 1_048_576
+    torch.manual_seed(5)
+    z = torch.randn(n, 2, device=dev)
+    with torch.no_grad():
+        x, lp = gen.sample_and_log_prob(n, z=z)
+    assert torch.isfinite(x).all() and torch.isfinite(lp).all()
+    # round trip and density consistency
+    err = (gen.inverse(x) - z).abs()
+    assert err.median() < 2e-6 and err.quantile(0.999) < 1e-3
+    dl = (gen.log_prob(x) - lp).abs()
+    assert dl.median() < 2e-5 and dl.quantile(0.999) < 5e-3
+    # histograms: additive over a split of the batch, normalised to one
+    diag = prob.diagnostics[0][0]
+    V = torch.stack([t.matrix[0] for t in prob.transforms]).contiguous()
+    R = ops.kde_radius(0.5)
+    S = ops.ProjKde1dFn.apply(x, V, diag.coords, float(diag.bandwidth), R)
+    Sa = ops.ProjKde1dFn.apply(x[:400_001].contiguous(), V, diag.coords, float(diag.bandwidth), R)
+    Sb = ops.ProjKde1dFn.apply(x[400_001:].contiguous(), V, diag.coords, float(diag.bandwidth), R)
+    torch.testing.assert_close(S, Sa + Sb, rtol=3e-7, atol=1e-6)
+    # the whole loss: fused vs two-kernel backward, and bitwise run-to-run reproducibility of the parameter gradients
+    grads = []
+    for fused in ("1", "1", "0"):
+        monkeypatch.setenv("MENTFLOW_BWD_FUSED", fused)
+        gen.inject_z = z
+        prob.model.zero_grad()
+        L, H, D = prob.model.loss(n)
+        L.backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).clone())
+    monkeypatch.delenv("MENTFLOW_BWD_FUSED")
+    assert torch.equal(grads[0], grads[1]), "parameter gradients are not bitwise reproducible"
+    torch.testing.assert_close(grads[0], grads[2], rtol=2e-4, atol=2e-5 * float(grads[0].abs().max()))
+
+
+def test_16m_particles_indexing_smoke(dev):
+    """C4's GLOBAL batch on one GPU (the strong-scaling N = 1 point): 16 777 216 particles through the flow forward,
+    the 100-projection KDE forward / backward and the fused flow backward.  Checks the 64-bit indexing and the grid-stride
+    arithmetic against the same computation done in 8 shards of 2 097 152 (what 8 ranks would each do)."""
+    prob = build_problem(ndim=6, num=100, bins=64, xmax=3.5, seed=0, transforms=5, prior_scale=3.0, device=dev,
+                         dist_name="gaussian_mixture", meas_samples=200_000, penalty_parameter=500.0)
+    gen = prob.model.generator
+    diag = prob.diagnostics[0][0]
+    V = torch.stack([t.matrix[0] for t in prob.transforms]).contiguous()
+    n, shards = 16_777_216, 8
+    m = n // shards
+    torch.manual_seed(9)
+    z = torch.randn(n, 6, device=dev)
+    R = ops.kde_radius(0.5)
+    coef = torch.randn(100, 64, device=dev)
+
+    def run(zz):
+        gen.zero_grad()
+        zz = zz.contiguous()
+        x, lp = gen.sample_and_log_prob(zz.shape[0], z=zz)
+        xd = x.detach().requires_grad_(True)
+        S = ops.ProjKde1dFn.apply(xd, V, diag.coords, float(diag.bandwidth), R)
+        (S * coef).sum().backward()
+        gx = xd.grad
+        ((x * gx).sum() / n + lp.sum() / n).backward()
+        g = torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).double()
+        return x.detach(), lp.detach(), S.detach().double(), gx, g
+
+    x, lp, S, gx, g = run(z)
+    assert torch.isfinite(x).all() and torch.isfinite(lp).all() and torch.isfinite(gx).all()
+    S_sum = torch.zeros_like(S)
+    g_sum = torch.zeros_like(g)
+    for k in range(shards):
+        xs, lps, Ss, gxs, gs = run(z[k * m:(k + 1) * m])
+        assert torch.equal(xs, x[k * m:(k + 1) * m]) and torch.equal(lps, lp[k * m:(k + 1) * m])
+        assert torch.equal(gxs, gx[k * m:(k + 1) * m])
+        S_sum += Ss
+        g_sum += gs
+    torch.testing.assert_close(S, S_sum, rtol=1e-6, atol=1e-5)
+    torch.testing.assert_close(g, g_sum, rtol=1e-4, atol=1e-5 * float(g.abs().max()))
+    # the tail end of the batch really was processed (last particle's row is not an uninitialised buffer)
+    assert float(gx[-1].abs().sum()) > 0 and float(x[-1].abs().sum()) > 0
