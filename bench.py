@@ -34,9 +34,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 PEAK_MFMA_F32 = 157.3          # TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (fp32-input MFMA, dense)
 PEAK_HBM = 8000.0              # GB/s spec
-# 64-bit LDS atomic adds a CU sustains per clock (tools/ubench_lds_atomics.hip on MI355X, profiles/r01 README): the KDE
+# 64-bit LDS atomic adds a CU sustains per clock with enough waves in flight, whatever the address pattern
+# (tools/ubench_lds_atomics2.hip on MI355X, profiles/r02_ubench_lds_atomics2.txt: 3.8-3.9 lane-ops/clk/CU): the KDE
 # forward kernels are bound by this, not by HBM
-LDS_ATOMIC_U64_PER_CLK_CU = 2.7
+LDS_ATOMIC_U64_PER_CLK_CU = 3.9
 CLOCK_GHZ = 2.4
 NUM_CU = 256
 
@@ -383,7 +384,7 @@ def run_worker(args) -> int:
             elif dom.endswith("_fwd"):
                 # KDE forward: every particle adds (2R+1) [1-D] or (2R+1)^2 [2-D] fixed-point weights per projection with
                 # 64-bit LDS atomics; the ceiling is the measured ds_add_u64 issue rate of the chip, not HBM
-                ops_pp = P * (9 if dom == "kde1d_fwd" else 81)
+                ops_pp = P * (9 if dom == "kde1d_fwd" else 69)       # window cells visited (2-D: 81 - 12 dead corners)
                 peak = LDS_ATOMIC_U64_PER_CLK_CU * NUM_CU * CLOCK_GHZ            # G lane-atomics / s
                 roof.update(bound="lds_atomic", unit="G ds_add_u64/s", peak=peak,
                             achieved=ops_pp * per_launch_particles / avg_s / 1e9,

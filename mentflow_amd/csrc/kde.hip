@@ -9,16 +9,19 @@
 //   kl_divergence / mae / mse        mentflow/loss.py:7-17
 //   MonteCarloEntropyEstimator       mentflow/entropy.py:58-62, prior.Gaussian mentflow/prior.py:25-26
 //
-// Design (HBM-bound byte work; no MFMA here): one lane per particle, particle rows read once (coalesced,
-// d floats per lane), projection vectors / bin centres / the histogram image of a group of projections live in
-// LDS; every particle touches only the 2R+1 bins whose Gaussian weight is above fp32 resolution (sigma = bw*delta,
-// R = ceil(9 bw - 1/2): dropped weights < 3e-18).
-// Accumulation inside a workgroup is FIXED POINT: each weight (<= 1) is converted to a 2^-50 integer and added with
-// 64-bit integer LDS atomics (order independent, 8.9e-16 quantum: far-tail bins, whose log enters the KL
-// discrepancy, keep their relative accuracy); the
-// per-workgroup sums are flushed with one fp64 global atomic per bin and rounded to fp32 once at the end.
-// Measured on MI355X (tools/ubench_lds_atomics.hip): ds_add_f32 sustains 0.33 lane-ops/clk/CU, ds_add_u64 2.7 — the
-// float LDS atomic is 8x slower.
+// Design (no MFMA here; the forward kernels are bound by LDS-atomic issue, the backward ones by LDS gathers / HBM rows):
+// one lane per particle, particle rows read once (coalesced, d floats per lane), projection vectors / bin centres /
+// the histogram image of a group of projections live in LDS; every particle touches only the 2R+1 bins whose Gaussian
+// weight is above fp32 resolution (sigma = bw*delta, R = ceil(9 bw - 1/2): dropped weights < 3e-18).
+// Accumulation is FIXED POINT and therefore exact and order independent at every level: each weight (<= 1) is
+// converted to a 2^-50 integer and added with 64-bit integer LDS atomics (8.9e-16 quantum: far-tail bins, whose log
+// enters the KL discrepancy, keep their relative accuracy); a workgroup (<= 8192 particles: 2^13 * 2^50 < 2^64) flushes
+// the low and the high 32 bits of every non-zero bin with two 64-bit INTEGER global atomics, and a finishing kernel
+// rebuilds hi * 2^32 + lo, scales by 2^-50 and rounds to fp32 once.  The histograms are bitwise reproducible.
+// Measured on MI355X (tools/ubench_lds_atomics*.hip): ds_add_f32 sustains 0.33 lane-ops/clk/CU, ds_add_u64 2.7 with
+// random addresses (bank conflicts between the 16 lanes of a group) — the float LDS atomic is 8x slower.  The image can
+// be REPLICATED (COPIES = 1, 2, 4, 8, 16): copy c = lane & (COPIES - 1) of entry e lives at e * COPIES + c, so the lanes
+// of a 16-lane group are spread over the LDS banks whatever bins they hit (16 copies: conflict-free by construction).
 #include "common.h"
 
 namespace mf {
@@ -51,8 +54,10 @@ __device__ __forceinline__ int centre_bin(float u, float c0, float inv_delta, in
 // ------------------------------------------------------------------------------------------------ 1-D forward
 typedef unsigned long long u64;
 constexpr double KDE_FIX_INV = 1.0 / 1125899906842624.0; // 2^-50: fixed-point quantum of the LDS histogram image
-constexpr int KDE_MAX_PER_WG = 4096;                     // particles per workgroup: 2^12 * 2^50 < 2^63, no overflow
+constexpr float KDE_FIX_MIN = 8.8817841970012523e-16f;   // 2^-50: smaller weights round down to zero
+constexpr int KDE_MAX_PER_WG = 8192;                     // particles per workgroup: 2^13 * 2^50 < 2^64, no overflow
 constexpr float KDE_EXP2_SCALE = 0.7213475204444817f;    // log2(e) / 2:  exp(-r^2/2) = exp2(-KDE_EXP2_SCALE r^2)
+constexpr int KDE_VS = 8;                                // LDS row stride of the projection vectors (two 16-byte reads)
 
 __device__ __forceinline__ float gauss_weight(float r) { return __builtin_amdgcn_exp2f(-KDE_EXP2_SCALE * r * r); }
 
@@ -64,88 +69,163 @@ __device__ __forceinline__ u64 to_fix(float w) {
     return ((u64)hi << 32) | (u64)lo;
 }
 
-// grid (G, ngroups); LDS: [Pg*B] u64 image | [Pg*ds] V (row stride ds = d|1, odd) | [B] coords
-template <int RT>   // RT > 0: compile-time window radius (unrolled);  RT == 0: runtime radius
-__global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_fwd_kernel(
+// exact flush of one workgroup's bin total v (< 2^64) into the global accumulator pair [lo | hi] of the bin
+__device__ __forceinline__ void fix_flush(u64* __restrict__ acc2, u64 v) {
+    if (v != 0) {
+        atomicAdd(&acc2[0], v & 0xffffffffull);
+        const u64 hi = v >> 32;
+        if (hi != 0) atomicAdd(&acc2[1], hi);
+    }
+}
+
+// Gaussian window on a UNIFORM grid, factorised: with kc the centre bin of u, r0 = (u - c_kc) / sigma and
+// s = delta / sigma, bin kc + j sits at r_j = r0 - j s and
+//     w_j = exp(-r_j^2 / 2) = A rho^j gam_j,   A = exp(-r0^2/2),  rho = exp(s r0),  gam_j = exp(-j^2 s^2 / 2)
+// — three v_exp (quarter rate) per particle and projection instead of 2 RT + 1.  |s r0| <= s^2 / 2, and RT = 4 is only
+// used for bandwidths in (0.389, 0.5] bin widths (s in [2, 2.57]): rho^4 <= 5.4e5, nothing overflows.  The bin centres are
+// taken as c_kc + j delta (the table rounds each centre separately: |dr| <= 4.4e-6, relative weight change <= r dr, i.e.
+// 1e-6 of a bin total — inside the fp32 tolerance of the tests).
+template <int RT>
+struct GaussGamma {
+    float g[RT + 1];
+};
+template <int RT>
+__device__ __forceinline__ GaussGamma<RT> gauss_gamma(float s) {
+    GaussGamma<RT> gm;
+#pragma unroll
+    for (int j = 0; j <= RT; ++j) gm.g[j] = __builtin_amdgcn_exp2f(-KDE_EXP2_SCALE * (float)(j * j) * s * s);
+    return gm;
+}
+template <int RT>
+__device__ __forceinline__ void gauss_window(float r0, float s, const GaussGamma<RT>& gm, float (&w)[2 * RT + 1]) {
+    const float A = __builtin_amdgcn_exp2f(-KDE_EXP2_SCALE * r0 * r0);
+    const float e = 2.0f * KDE_EXP2_SCALE * s * r0;
+    const float rp = __builtin_amdgcn_exp2f(e), rm = __builtin_amdgcn_exp2f(-e);
+    w[RT] = A;
+    float pp = A, pm = A;
+#pragma unroll
+    for (int j = 1; j <= RT; ++j) {
+        pp *= rp;
+        pm *= rm;
+        w[RT + j] = pp * gm.g[j];
+        w[RT - j] = pm * gm.g[j];
+    }
+}
+// r0 of the (possibly virtual: kc may lie up to R + 2 bins outside [0, B)) centre bin
+__device__ __forceinline__ float centre_r0(float u, const float* cl, int kc, int B, float inv_sigma, float s) {
+    const int kk = min(max(kc, 0), B - 1);
+    return fmaf((float)(kk - kc), s, (u - cl[kk]) * inv_sigma);
+}
+
+__device__ __forceinline__ void load_vrow(const float* Vl, int q, float (&v)[KDE_DMAX]) {
+    const float4 a = *reinterpret_cast<const float4*>(Vl + q * KDE_VS);
+    const float4 b = *reinterpret_cast<const float4*>(Vl + q * KDE_VS + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ float project8(const float (&xv)[KDE_DMAX], const float (&v)[KDE_DMAX]) {
+    float u = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KDE_DMAX; ++j) u = fmaf(xv[j], v[j], u);     // columns >= d: xv = 0, v = 0
+    return u;
+}
+template <int BLOCK>
+__device__ __forceinline__ void stage_vrows(float* Vl, const float* __restrict__ V, int p_begin, int np, int d) {
+    for (int i = threadIdx.x; i < np * KDE_VS; i += BLOCK) {
+        const int q = i / KDE_VS, j = i - q * KDE_VS;
+        Vl[i] = (j < d) ? V[(p_begin + q) * d + j] : 0.0f;
+    }
+}
+
+// grid (G, ngroups); block BLOCK; workgroup (bx, by) takes particles [bx * per_wg, (bx + 1) * per_wg) and the
+// projections of group by.  LDS: [Pg * B] u64 image | [Pg * 8] V | [B] coords.  All lanes of a wave work on the SAME
+// projection at a time (its row of V is a broadcast LDS read): LDS atomics sustain the same ~3.5-3.9 lane-ops/clk/CU
+// whether the lanes' addresses are spread, random or piled on one row (tools/ubench_lds_atomics2.hip), so nothing is
+// gained by staggering the lanes over projections, and bank conflicts do not matter either.
+template <int RT, int BLOCK>   // RT > 0: compile-time window radius (factorised weights);  RT == 0: runtime radius
+__global__ __launch_bounds__(BLOCK) void proj_kde1d_fwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V, int P, int Pg,
-    const float* __restrict__ coords, int B, float inv_sigma, int Rrt, double* __restrict__ Sacc) {
+    const float* __restrict__ coords, int B, float inv_sigma, int Rrt, u64* __restrict__ Sacc, int per_wg) {
     MF_DYN_SMEM(u64, lds);
     u64* img = lds;
-    const int ds = d | 1;
-    float* Vl = reinterpret_cast<float*>(img + Pg * B);
-    float* cl = Vl + Pg * ds;
+    float* Vl = reinterpret_cast<float*>(img + (size_t)Pg * B);
+    float* cl = Vl + Pg * KDE_VS;
     const int p_begin = blockIdx.y * Pg;
     const int np = min(Pg, P - p_begin);
     const int R = RT > 0 ? RT : Rrt;
-    for (int i = threadIdx.x; i < np * B; i += KDE_BLOCK) img[i] = 0;
-    for (int i = threadIdx.x; i < np * d; i += KDE_BLOCK) Vl[(i / d) * ds + (i % d)] = V[p_begin * d + i];
-    for (int i = threadIdx.x; i < B; i += KDE_BLOCK) cl[i] = coords[i];
+    for (int i = threadIdx.x; i < np * B; i += BLOCK) img[i] = 0;
+    stage_vrows<BLOCK>(Vl, V, p_begin, np, d);
+    for (int i = threadIdx.x; i < B; i += BLOCK) cl[i] = coords[i];
     __syncthreads();
     const float c0 = cl[0];
-    const float inv_delta = 1.0f / (cl[1] - cl[0]);
-    for (int64_t p = (int64_t)blockIdx.x * KDE_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * KDE_BLOCK) {
+    const float delta = cl[1] - cl[0];
+    const float inv_delta = 1.0f / delta;
+    const float s = delta * inv_sigma;
+    const GaussGamma<(RT > 0 ? RT : 1)> gm = gauss_gamma<(RT > 0 ? RT : 1)>(s);
+    const int64_t p_lo = (int64_t)blockIdx.x * per_wg;
+    const int64_t p_hi = min(n, p_lo + per_wg);
+    for (int64_t p = p_lo + threadIdx.x; p < p_hi; p += BLOCK) {
         float xv[KDE_DMAX];
         load_row(x, p, d, xv);
-        // every lane starts at a different projection: the 64 lanes of a wave then add into different rows of the
-        // image instead of piling onto the few populated bins of one projection
-        int q = (int)(threadIdx.x % (unsigned)np);
-        for (int it = 0; it < np; ++it) {
-            const float u = project(xv, Vl + q * ds, d);
+        for (int q = 0; q < np; ++q) {
+            float vq[KDE_DMAX];
+            load_vrow(Vl, q, vq);
+            const float u = project8(xv, vq);
             const int kc = centre_bin(u, c0, inv_delta, B, R);
-            u64* row = img + q * B;
+            u64* row = img + (size_t)q * B;
             if (RT > 0) {
+                float w[2 * (RT > 0 ? RT : 1) + 1];
+                gauss_window<(RT > 0 ? RT : 1)>(centre_r0(u, cl, kc, B, inv_sigma, s), s, gm, w);
 #pragma unroll
                 for (int j = -RT; j <= RT; ++j) {
                     const int k = kc + j;
                     if (k >= 0 && k < B) {
-                        const float w = gauss_weight((u - cl[k]) * inv_sigma);
-                        atomicAdd(&row[k], to_fix(w));
+                        const u64 f = to_fix(w[j + RT]);
+                        if (f != 0) atomicAdd(&row[k], f);
                     }
                 }
             } else {
                 for (int j = -R; j <= R; ++j) {
                     const int k = kc + j;
                     if (k >= 0 && k < B) {
-                        const float w = gauss_weight((u - cl[k]) * inv_sigma);
-                        atomicAdd(&row[k], to_fix(w));
+                        const u64 f = to_fix(gauss_weight((u - cl[k]) * inv_sigma));
+                        if (f != 0) atomicAdd(&row[k], f);
                     }
                 }
             }
-            q = (q + 1 == np) ? 0 : q + 1;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < np * B; i += KDE_BLOCK) {
-        const u64 v = img[i];
-        if (v != 0) atomicAdd(&Sacc[(int64_t)p_begin * B + i], (double)v * KDE_FIX_INV);
-    }
+    for (int i = threadIdx.x; i < np * B; i += BLOCK) fix_flush(Sacc + 2 * ((int64_t)p_begin * B + i), img[i]);
 }
 
-__global__ __launch_bounds__(KDE_BLOCK) void acc_to_float_kernel(const double* __restrict__ Sacc, float* __restrict__ S,
+// S[i] = fp32( (hi * 2^32 + lo) * 2^-50 )
+__global__ __launch_bounds__(KDE_BLOCK) void acc_to_float_kernel(const u64* __restrict__ Sacc, float* __restrict__ S,
                                                                   int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * KDE_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * KDE_BLOCK)
-        S[i] = (float)Sacc[i];
+        S[i] = (float)(((double)Sacc[2 * i + 1] * 4294967296.0 + (double)Sacc[2 * i]) * KDE_FIX_INV);
 }
 
 // ------------------------------------------------------------------------------------------------ 1-D backward
-// grid (G); loops over projection groups; LDS: [Pg*B] gS | [Pg*d] V | [B] coords.
+// grid (G); loops over projection groups; LDS: [Pg*B] gS | [Pg*8] V | [B] coords.
 // CH (1, 2, 4 or 8) adjacent lanes share a particle and take every CH-th projection; their partial gradient rows are
 // summed with a fixed butterfly (deterministic, no atomics).  Small batches use CH > 1: one lane per particle walks
 // all P projections serially, which leaves most of the chip idle at the reference's 25 000-particle batch.
-template <int RT>   // RT > 0: compile-time window radius (unrolled, branch-free);  RT == 0: runtime radius
-__global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
+template <int RT, int BLOCK>   // RT > 0: compile-time window radius (factorised, branch-free);  RT == 0: runtime radius
+__global__ __launch_bounds__(BLOCK) void proj_kde1d_bwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V, int P, int Pg,
     const float* __restrict__ coords, int B, float inv_sigma, int R, const float* __restrict__ gS,
     float* __restrict__ gx, int accumulate, int CH) {
     MF_DYN_SMEM(float, lds);
     float* img = lds;
     float* Vl = img + Pg * B;
-    float* cl = Vl + Pg * d;
-    for (int i = threadIdx.x; i < B; i += KDE_BLOCK) cl[i] = coords[i];
+    float* cl = Vl + Pg * KDE_VS;
+    for (int i = threadIdx.x; i < B; i += BLOCK) cl[i] = coords[i];
     __syncthreads();
     const float c0 = cl[0];
-    const float inv_delta = 1.0f / (cl[1] - cl[0]);
-    const int per_wg = KDE_BLOCK / CH;
+    const float delta = cl[1] - cl[0];
+    const float inv_delta = 1.0f / delta;
+    const int per_wg = BLOCK / CH;
     const int chunk = threadIdx.x % CH;
     const int64_t p = (int64_t)blockIdx.x * per_wg + threadIdx.x / CH;
     const bool valid = p < n;
@@ -156,22 +236,28 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
     for (int p_begin = 0; p_begin < P; p_begin += Pg) {
         const int np = min(Pg, P - p_begin);
         __syncthreads();
-        for (int i = threadIdx.x; i < np * B; i += KDE_BLOCK) img[i] = gS[(int64_t)p_begin * B + i];
-        for (int i = threadIdx.x; i < np * d; i += KDE_BLOCK) Vl[i] = V[p_begin * d + i];
+        for (int i = threadIdx.x; i < np * B; i += BLOCK) img[i] = gS[(int64_t)p_begin * B + i];
+        stage_vrows<BLOCK>(Vl, V, p_begin, np, d);
         __syncthreads();
         for (int q = chunk; q < np; q += CH) {
-            const float u = project(xv, Vl + q * d, d);
+            float vq[KDE_DMAX];
+            load_vrow(Vl, q, vq);
+            const float u = project8(xv, vq);
             const int kc = centre_bin(u, c0, inv_delta, B, R);
             float du = 0.0f;
             if (RT > 0) {
-                // window bins outside [0, B) read a clamped bin with weight 0: no divergent branch in the unrolled loop
+                // window bins outside [0, B) read a clamped bin and are masked: no divergent branch in the unrolled loop
+                // (NaN / inf rows: every bin is out of range, every term is masked, the gradient row is exactly 0)
+                // residuals from the table of bin centres, exactly as the reference forms them (the backward is VALU /
+                // gather bound, not atomic bound: the factorised window of the forward would only save exps here, at the
+                // price of a 4e-6 absolute error in per-particle gradients from the table's rounding)
 #pragma unroll
                 for (int j = -RT; j <= RT; ++j) {
                     const int k = kc + j;
                     const int kk = min(max(k, 0), B - 1);
-                    const float r = (k == kk) ? (u - cl[kk]) * inv_sigma : 0.0f;   // masked too: u may be inf / NaN
-                    const float g = (k == kk) ? img[q * B + kk] : 0.0f;
-                    du = fmaf(g * gauss_weight(r), -r * inv_sigma, du);
+                    const float r = (u - cl[kk]) * inv_sigma;
+                    const float term = img[q * B + kk] * gauss_weight(r) * (-r * inv_sigma);
+                    du += (k == kk) ? term : 0.0f;
                 }
             } else {
                 for (int j = -R; j <= R; ++j) {
@@ -183,8 +269,7 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
                 }
             }
 #pragma unroll
-            for (int j = 0; j < KDE_DMAX; ++j)
-                if (j < d) gv[j] = fmaf(du, Vl[q * d + j], gv[j]);
+            for (int j = 0; j < KDE_DMAX; ++j) gv[j] = fmaf(du, vq[j], gv[j]);
         }
     }
     for (int m = 1; m < CH; m <<= 1) {
@@ -199,75 +284,109 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde1d_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ 2-D forward
-// grid (G, ngroups); LDS: [Pg*Bx*By] u64 image | [Pg*ds] V0 | [Pg*ds] V1 | [Bx] cx | [By] cy
-__global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_fwd_kernel(
+// Window cells (i, j) bins away from the centre cell whose weight is below the 2^-50 quantum WHATEVER the position of
+// the particle inside its cell: (|i| - 1/2)^2 + (|j| - 1/2)^2 > 2 * 50 ln 2 / s^2 with s >= 2 (radius-4 windows), i.e.
+// > 17.33 bins^2 — the four corners (4,4) and the eight (4,3)/(3,4) cells.  They are never visited.
+__device__ __forceinline__ constexpr bool kde2d_dead_cell(int i, int j) {
+    const int a = i < 0 ? -i : i, b = j < 0 ? -j : j;
+    return (a >= 1 && b >= 1) && ((2 * a - 1) * (2 * a - 1) + (2 * b - 1) * (2 * b - 1) > 69);   // 4 * 17.33
+}
+
+// grid (G, ngroups); workgroup (bx, by): particles [bx * per_wg, ...), projections of group by.
+// LDS: [Pg*Bx*By] u64 image | [Pg*8] V0 | [Pg*8] V1 | [Bx] cx | [By] cy
+template <int RT, int BLOCK>   // RT == 4: both radii are 4 (factorised weights, dead corners skipped);  RT == 0: generic
+__global__ __launch_bounds__(BLOCK) void proj_kde2d_fwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V0, const float* __restrict__ V1, int P,
     int Pg, const float* __restrict__ coords_x, int Bx, float inv_sx, int Rx, const float* __restrict__ coords_y,
-    int By, float inv_sy, int Ry, double* __restrict__ Sacc) {
+    int By, float inv_sy, int Ry, u64* __restrict__ Sacc, int per_wg) {
     MF_DYN_SMEM(u64, lds);
     const int BB = Bx * By;
-    const int ds = d | 1;
     u64* img = lds;
-    float* V0l = reinterpret_cast<float*>(img + Pg * BB);
-    float* V1l = V0l + Pg * ds;
-    float* cxl = V1l + Pg * ds;
+    float* V0l = reinterpret_cast<float*>(img + (size_t)Pg * BB);
+    float* V1l = V0l + Pg * KDE_VS;
+    float* cxl = V1l + Pg * KDE_VS;
     float* cyl = cxl + Bx;
     const int p_begin = blockIdx.y * Pg;
     const int np = min(Pg, P - p_begin);
-    for (int i = threadIdx.x; i < np * BB; i += KDE_BLOCK) img[i] = 0;
-    for (int i = threadIdx.x; i < np * d; i += KDE_BLOCK) {
-        V0l[(i / d) * ds + (i % d)] = V0[p_begin * d + i];
-        V1l[(i / d) * ds + (i % d)] = V1[p_begin * d + i];
-    }
-    for (int i = threadIdx.x; i < Bx; i += KDE_BLOCK) cxl[i] = coords_x[i];
-    for (int i = threadIdx.x; i < By; i += KDE_BLOCK) cyl[i] = coords_y[i];
+    for (int i = threadIdx.x; i < np * BB; i += BLOCK) img[i] = 0;
+    stage_vrows<BLOCK>(V0l, V0, p_begin, np, d);
+    stage_vrows<BLOCK>(V1l, V1, p_begin, np, d);
+    for (int i = threadIdx.x; i < Bx; i += BLOCK) cxl[i] = coords_x[i];
+    for (int i = threadIdx.x; i < By; i += BLOCK) cyl[i] = coords_y[i];
     __syncthreads();
-    const float cx0 = cxl[0], inv_dx = 1.0f / (cxl[1] - cxl[0]);
-    const float cy0 = cyl[0], inv_dy = 1.0f / (cyl[1] - cyl[0]);
-    for (int64_t p = (int64_t)blockIdx.x * KDE_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * KDE_BLOCK) {
+    const float cx0 = cxl[0], dx = cxl[1] - cxl[0], inv_dx = 1.0f / dx, ssx = dx * inv_sx;
+    const float cy0 = cyl[0], dy = cyl[1] - cyl[0], inv_dy = 1.0f / dy, ssy = dy * inv_sy;
+    constexpr int RW = RT > 0 ? RT : 1;
+    const GaussGamma<RW> gmx = gauss_gamma<RW>(ssx), gmy = gauss_gamma<RW>(ssy);
+    const int64_t p_lo = (int64_t)blockIdx.x * per_wg;
+    const int64_t p_hi = min(n, p_lo + per_wg);
+    for (int64_t p = p_lo + threadIdx.x; p < p_hi; p += BLOCK) {
         float xv[KDE_DMAX];
         load_row(x, p, d, xv);
         for (int q = 0; q < np; ++q) {
-            const float u0 = project(xv, V0l + q * ds, d);
-            const float u1 = project(xv, V1l + q * ds, d);
+            float v0[KDE_DMAX], v1[KDE_DMAX];
+            load_vrow(V0l, q, v0);
+            load_vrow(V1l, q, v1);
+            const float u0 = project8(xv, v0);
+            const float u1 = project8(xv, v1);
             const int ka = centre_bin(u0, cx0, inv_dx, Bx, Rx);
             const int kb = centre_bin(u1, cy0, inv_dy, By, Ry);
-            float wy[2 * KDE_RMAX2D + 1];
+            u64* im = img + (size_t)q * BB;
+            if (RT > 0) {
+                float wx[2 * RW + 1], wy[2 * RW + 1];
+                gauss_window<RW>(centre_r0(u0, cxl, ka, Bx, inv_sx, ssx), ssx, gmx, wx);
+                gauss_window<RW>(centre_r0(u1, cyl, kb, By, inv_sy, ssy), ssy, gmy, wy);
 #pragma unroll
-            for (int j = 0; j < 2 * KDE_RMAX2D + 1; ++j) {
-                const int b = kb - Ry + j;
-                float w = 0.0f;
-                if (j <= 2 * Ry && b >= 0 && b < By) w = gauss_weight((u1 - cyl[b]) * inv_sy);
-                wy[j] = w;
-            }
-            for (int i = 0; i <= 2 * Rx; ++i) {
-                const int a = ka - Rx + i;
-                if (a < 0 || a >= Bx) continue;
-                const float wx = gauss_weight((u0 - cxl[a]) * inv_sx);
-                u64* row = img + q * BB + a * By;
+                for (int i = -RT; i <= RT; ++i) {
+                    const int a = ka + i;
+                    if (a < 0 || a >= Bx) continue;
+                    u64* row = im + a * By;
+#pragma unroll
+                    for (int j = -RT; j <= RT; ++j) {
+                        if (kde2d_dead_cell(i, j)) continue;
+                        const int b = kb + j;
+                        if (b >= 0 && b < By) {
+                            const u64 f = to_fix(wx[i + RW] * wy[j + RW]);
+                            if (f != 0) atomicAdd(&row[b], f);
+                        }
+                    }
+                }
+            } else {
+                float wy[2 * KDE_RMAX2D + 1];
 #pragma unroll
                 for (int j = 0; j < 2 * KDE_RMAX2D + 1; ++j) {
                     const int b = kb - Ry + j;
-                    if (j <= 2 * Ry && b >= 0 && b < By) atomicAdd(&row[b], to_fix(wx * wy[j]));
+                    float w = 0.0f;
+                    if (j <= 2 * Ry && b >= 0 && b < By) w = gauss_weight((u1 - cyl[b]) * inv_sy);
+                    wy[j] = w;
+                }
+                for (int i = 0; i <= 2 * Rx; ++i) {
+                    const int a = ka - Rx + i;
+                    if (a < 0 || a >= Bx) continue;
+                    const float wx = gauss_weight((u0 - cxl[a]) * inv_sx);
+                    u64* row = im + a * By;
+#pragma unroll
+                    for (int j = 0; j < 2 * KDE_RMAX2D + 1; ++j) {
+                        const int b = kb - Ry + j;
+                        if (j <= 2 * Ry && b >= 0 && b < By) {
+                            const u64 f = to_fix(wx * wy[j]);
+                            if (f != 0) atomicAdd(&row[b], f);
+                        }
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < np * BB; i += KDE_BLOCK) {
-        const u64 v = img[i];
-        if (v != 0) atomicAdd(&Sacc[(int64_t)p_begin * BB + i], (double)v * KDE_FIX_INV);
-    }
+    for (int i = threadIdx.x; i < np * BB; i += BLOCK) fix_flush(Sacc + 2 * ((int64_t)p_begin * BB + i), img[i]);
 }
 
 // ------------------------------------------------------------------------------------------------ 2-D backward
-// A workgroup owns KDE2D_BWD_NPT * 256 particles and walks the projection groups once.  Every thread keeps the rows and
-// the gradient rows of its KDE2D_BWD_NPT particles in registers for the whole walk (no read-modify-write of gx per
-// group); the gS images of a group are staged into LDS once per workgroup and group.  The group size is chosen so that
-// the image stays under ~40 KB (one 85 x 85 image): several workgroups then share a CU and hide the latency of the
-// data-dependent LDS reads (one workgroup per CU with five images was 2.7x slower).
-constexpr int KDE2D_BWD_NPT = 4;
-__global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
+// A workgroup owns NPT * BLOCK particles and walks the projection groups once.  Every thread keeps the rows and the
+// gradient rows of its NPT particles in registers for the whole walk (no read-modify-write of gx per group); the gS
+// images of a group are staged into LDS once per workgroup and group.
+template <int RT, int BLOCK, int NPT>
+__global__ __launch_bounds__(BLOCK) void proj_kde2d_bwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V0, const float* __restrict__ V1, int P,
     int Pg, const float* __restrict__ coords_x, int Bx, float inv_sx, int Rx, const float* __restrict__ coords_y,
     int By, float inv_sy, int Ry, const float* __restrict__ gS, float* __restrict__ gx, int accumulate) {
@@ -275,19 +394,20 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
     const int BB = Bx * By;
     float* img = lds;
     float* V0l = img + Pg * BB;
-    float* V1l = V0l + Pg * d;
-    float* cxl = V1l + Pg * d;
+    float* V1l = V0l + Pg * KDE_VS;
+    float* cxl = V1l + Pg * KDE_VS;
     float* cyl = cxl + Bx;
-    for (int i = threadIdx.x; i < Bx; i += KDE_BLOCK) cxl[i] = coords_x[i];
-    for (int i = threadIdx.x; i < By; i += KDE_BLOCK) cyl[i] = coords_y[i];
+    for (int i = threadIdx.x; i < Bx; i += BLOCK) cxl[i] = coords_x[i];
+    for (int i = threadIdx.x; i < By; i += BLOCK) cyl[i] = coords_y[i];
     __syncthreads();
     const float cx0 = cxl[0], inv_dx = 1.0f / (cxl[1] - cxl[0]);
     const float cy0 = cyl[0], inv_dy = 1.0f / (cyl[1] - cyl[0]);
-    const int64_t base = (int64_t)blockIdx.x * KDE_BLOCK * KDE2D_BWD_NPT + threadIdx.x;
-    float xv[KDE2D_BWD_NPT][KDE_DMAX], gv[KDE2D_BWD_NPT][KDE_DMAX];
+    constexpr int RW = RT > 0 ? RT : 1;
+    const int64_t base = (int64_t)blockIdx.x * BLOCK * NPT + threadIdx.x;
+    float xv[NPT][KDE_DMAX], gv[NPT][KDE_DMAX];
 #pragma unroll
-    for (int t = 0; t < KDE2D_BWD_NPT; ++t) {
-        const int64_t p = base + (int64_t)t * KDE_BLOCK;
+    for (int t = 0; t < NPT; ++t) {
+        const int64_t p = base + (int64_t)t * BLOCK;
         load_row(x, p < n ? p : n - 1, d, xv[t]);
 #pragma unroll
         for (int j = 0; j < KDE_DMAX; ++j) gv[t][j] = 0.0f;
@@ -295,62 +415,100 @@ __global__ __launch_bounds__(KDE_BLOCK) void proj_kde2d_bwd_kernel(
     for (int p_begin = 0; p_begin < P; p_begin += Pg) {
         const int np = min(Pg, P - p_begin);
         __syncthreads();
-        for (int i = threadIdx.x; i < np * BB; i += KDE_BLOCK) img[i] = gS[(int64_t)p_begin * BB + i];
-        for (int i = threadIdx.x; i < np * d; i += KDE_BLOCK) {
-            V0l[i] = V0[p_begin * d + i];
-            V1l[i] = V1[p_begin * d + i];
-        }
+        for (int i = threadIdx.x; i < np * BB; i += BLOCK) img[i] = gS[(int64_t)p_begin * BB + i];
+        stage_vrows<BLOCK>(V0l, V0, p_begin, np, d);
+        stage_vrows<BLOCK>(V1l, V1, p_begin, np, d);
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < KDE2D_BWD_NPT; ++t) {
+        for (int t = 0; t < NPT; ++t) {
             for (int q = 0; q < np; ++q) {
-                const float u0 = project(xv[t], V0l + q * d, d);
-                const float u1 = project(xv[t], V1l + q * d, d);
+                float v0[KDE_DMAX], v1[KDE_DMAX];
+                load_vrow(V0l, q, v0);
+                load_vrow(V1l, q, v1);
+                const float u0 = project8(xv[t], v0);
+                const float u1 = project8(xv[t], v1);
                 const int ka = centre_bin(u0, cx0, inv_dx, Bx, Rx);
                 const int kb = centre_bin(u1, cy0, inv_dy, By, Ry);
-                float wy[2 * KDE_RMAX2D + 1], dy[2 * KDE_RMAX2D + 1];
-#pragma unroll
-                for (int j = 0; j < 2 * KDE_RMAX2D + 1; ++j) {
-                    const int b = kb - Ry + j;
-                    float w = 0.0f, dw = 0.0f;
-                    if (j <= 2 * Ry && b >= 0 && b < By) {
-                        const float r = (u1 - cyl[b]) * inv_sy;
-                        w = gauss_weight(r);
-                        dw = -r * inv_sy * w;
-                    }
-                    wy[j] = w;
-                    dy[j] = dw;
-                }
+                const float* im = img + q * BB;
                 float du0 = 0.0f, du1 = 0.0f;
-                for (int i = 0; i <= 2 * Rx; ++i) {
-                    const int a = ka - Rx + i;
-                    if (a < 0 || a >= Bx) continue;
-                    const float r = (u0 - cxl[a]) * inv_sx;
-                    const float wx = gauss_weight(r);
-                    const float dwx = -r * inv_sx * wx;
-                    const float* row = img + q * BB + a * By;
-                    float sa = 0.0f, sb = 0.0f;
+                if (RT > 0) {
+                    // same cells as the forward (dead corners skipped); out-of-range bins read a clamped bin, masked
+                    // residuals from the tables of bin centres, exactly as the reference forms them
+                    float wy[2 * RW + 1], dyw[2 * RW + 1];
+                    int bidx[2 * RW + 1];
+#pragma unroll
+                    for (int j = -RT; j <= RT; ++j) {
+                        const int b = kb + j;
+                        const int bb = min(max(b, 0), By - 1);
+                        const bool ok = b == bb;
+                        const float r = (u1 - cyl[bb]) * inv_sy;
+                        const float w = ok ? gauss_weight(r) : 0.0f;       // select, not multiply: NaN rows stay out
+                        wy[j + RW] = w;
+                        dyw[j + RW] = ok ? -r * inv_sy * w : 0.0f;
+                        bidx[j + RW] = bb;
+                    }
+#pragma unroll
+                    for (int i = -RT; i <= RT; ++i) {
+                        const int a = ka + i;
+                        const int aa = min(max(a, 0), Bx - 1);
+                        const float* row = im + aa * By;
+                        float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+                        for (int j = -RT; j <= RT; ++j) {
+                            if (kde2d_dead_cell(i, j)) continue;
+                            const float g = row[bidx[j + RW]];
+                            sa = fmaf(g, wy[j + RW], sa);
+                            sb = fmaf(g, dyw[j + RW], sb);
+                        }
+                        const float r = (u0 - cxl[aa]) * inv_sx;
+                        const float w = gauss_weight(r);
+                        const float tx = -r * inv_sx * w * sa, ty = w * sb;
+                        du0 += (a == aa) ? tx : 0.0f;
+                        du1 += (a == aa) ? ty : 0.0f;
+                    }
+                } else {
+                    float wy[2 * KDE_RMAX2D + 1], dyv[2 * KDE_RMAX2D + 1];
 #pragma unroll
                     for (int j = 0; j < 2 * KDE_RMAX2D + 1; ++j) {
                         const int b = kb - Ry + j;
+                        float w = 0.0f, dw = 0.0f;
                         if (j <= 2 * Ry && b >= 0 && b < By) {
-                            const float g = row[b];
-                            sa = fmaf(g, wy[j], sa);
-                            sb = fmaf(g, dy[j], sb);
+                            const float r = (u1 - cyl[b]) * inv_sy;
+                            w = gauss_weight(r);
+                            dw = -r * inv_sy * w;
                         }
+                        wy[j] = w;
+                        dyv[j] = dw;
                     }
-                    du0 = fmaf(dwx, sa, du0);
-                    du1 = fmaf(wx, sb, du1);
+                    for (int i = 0; i <= 2 * Rx; ++i) {
+                        const int a = ka - Rx + i;
+                        if (a < 0 || a >= Bx) continue;
+                        const float r = (u0 - cxl[a]) * inv_sx;
+                        const float wx = gauss_weight(r);
+                        const float dwx = -r * inv_sx * wx;
+                        const float* row = im + a * By;
+                        float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 2 * KDE_RMAX2D + 1; ++j) {
+                            const int b = kb - Ry + j;
+                            if (j <= 2 * Ry && b >= 0 && b < By) {
+                                const float g = row[b];
+                                sa = fmaf(g, wy[j], sa);
+                                sb = fmaf(g, dyv[j], sb);
+                            }
+                        }
+                        du0 = fmaf(dwx, sa, du0);
+                        du1 = fmaf(wx, sb, du1);
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < KDE_DMAX; ++j)
-                    if (j < d) gv[t][j] = fmaf(du0, V0l[q * d + j], fmaf(du1, V1l[q * d + j], gv[t][j]));
+                for (int j = 0; j < KDE_DMAX; ++j) gv[t][j] = fmaf(du0, v0[j], fmaf(du1, v1[j], gv[t][j]));
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < KDE2D_BWD_NPT; ++t) {
-        const int64_t p = base + (int64_t)t * KDE_BLOCK;
+    for (int t = 0; t < NPT; ++t) {
+        const int64_t p = base + (int64_t)t * BLOCK;
         if (p < n) {
 #pragma unroll
             for (int j = 0; j < KDE_DMAX; ++j)
@@ -651,47 +809,82 @@ static int kde_check(int64_t n, int d, int P, int B) {
     return 0;
 }
 
-extern "C" int64_t mf_proj_kde_ws_bytes(int P, int bins) { return (int64_t)P * bins * (int64_t)sizeof(double); }
+// workspace of the forward kernels: one [lo | hi] pair of 64-bit integer accumulators per bin
+extern "C" int64_t mf_proj_kde_ws_bytes(int P, int bins) { return 2 * (int64_t)P * bins * (int64_t)sizeof(u64); }
 
-static int fix_finish(const double* Sacc, float* S, int64_t total, void* stream) {
+static int fix_finish(const u64* Sacc, float* S, int64_t total, void* stream) {
     MF_LAUNCH(acc_to_float_kernel, grid_for(total, KDE_BLOCK, 1024), KDE_BLOCK, 0, stream, Sacc, S, total);
     return check_launch("acc_to_float");
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+constexpr size_t KDE_LDS_BYTES = 156 * 1024;          // dynamic LDS a workgroup may ask for (of 160 KiB)
+
+// particles per forward workgroup: enough workgroups to cover the chip `waves` times over, a multiple of the block
+// size, at most KDE_MAX_PER_WG (fixed-point headroom)
+static int kde_per_wg(int64_t n, int ngroups, int block, int waves) {
+    int64_t want = (n * ngroups + (int64_t)waves * NUM_CU - 1) / ((int64_t)waves * NUM_CU);
+    want = ((want + block - 1) / block) * block;
+    if (want < block) want = block;
+    if (want > KDE_MAX_PER_WG) want = (KDE_MAX_PER_WG / block) * block;
+    return (int)want;
 }
 
 extern "C" int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* V, int P, const float* coords, int B,
                                   float sigma, int radius, float* S, void* ws, void* stream) {
     if (kde_check(n, d, P, B)) return 1;
-    const int budget = KDE_LDS_FLOATS / 2;            // 64-bit bins
-    if (B > budget) return fail("too many bins for the LDS image (%d)", B);
-    double* Sfix = reinterpret_cast<double*>(ws);
-    if (hipMemsetAsync(Sfix, 0, sizeof(double) * (size_t)P * B, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
+    u64* Sfix = reinterpret_cast<u64*>(ws);
+    if (hipMemsetAsync(Sfix, 0, 2 * sizeof(u64) * (size_t)P * B, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
     if (n > 0) {
         const int R = radius < 0 ? 0 : (radius > B ? B : radius);
-        int Pg = (budget / B) < P ? (budget / B) : P;
-        {   // small batches: more (smaller) projection groups, so that ~4 * NUM_CU workgroups exist
-            const int64_t wg_particles = (n + KDE_BLOCK - 1) / KDE_BLOCK;
+        const size_t per_proj = sizeof(u64) * (size_t)B + sizeof(float) * KDE_VS;
+        if (per_proj + sizeof(float) * B > KDE_LDS_BYTES) return fail("too many bins for the LDS image (%d)", B);
+        // Large batches: all projections that fit one image (C4: 100 x 64 bins = 51 KiB), big workgroups.  Small batches
+        // (the reference's 25 000 particles): 256 threads and many small projection groups so that ~4 * NUM_CU
+        // workgroups exist.
+        const bool small = n <= 65536;
+        // tuned on MI355X at C4 (tools/kde_sweep.py, profiles/r02_kde_sweep.txt): 1024 threads, ~52 KiB images (two
+        // workgroups = 32 waves per CU), 8 workgroup waves over the chip: 1.11 ms against 1.19-1.51 ms for 256 threads
+        static const int block_env = env_int("MENTFLOW_KDE1D_BLOCK", 0), waves_env = env_int("MENTFLOW_KDE1D_WAVES", 8);
+        static const int lds_env = env_int("MENTFLOW_KDE1D_LDS", 0);
+        const int block = block_env ? block_env : (small ? 256 : 1024);
+        size_t budget = lds_env ? (size_t)lds_env : (size_t)52 * 1024;
+        if (budget > KDE_LDS_BYTES) budget = KDE_LDS_BYTES;
+        int Pg = (int)((budget - sizeof(float) * B) / per_proj);
+        if (Pg < 1) Pg = 1;
+        if (Pg > P) Pg = P;
+        if (small) {
+            const int64_t wg_particles = (n + block - 1) / block;
             const int64_t want_groups = (4 * NUM_CU + wg_particles - 1) / wg_particles;
             if (want_groups > 1) {
                 int pg_small = (int)((P + want_groups - 1) / want_groups);
                 if (pg_small < 4) pg_small = P < 4 ? P : 4;
                 if (pg_small < Pg) Pg = pg_small;
             }
+        } else {
+            const int ng = (P + Pg - 1) / Pg;                 // equal-sized groups
+            Pg = (P + ng - 1) / ng;
         }
         const int ngroups = (P + Pg - 1) / Pg;
-        const int ds = d | 1;
-        const size_t smem = sizeof(u64) * (size_t)Pg * B + sizeof(float) * ((size_t)Pg * ds + B);
-        int G = grid_for(n, KDE_BLOCK, (NUM_CU * 8 + ngroups - 1) / ngroups);   // >= 256 particles per workgroup
-        if ((n + G - 1) / G > KDE_MAX_PER_WG) G = (int)((n + KDE_MAX_PER_WG - 1) / KDE_MAX_PER_WG);
+        const size_t smem = per_proj * Pg + sizeof(float) * B;
+        const int per_wg = small ? block : kde_per_wg(n, ngroups, block, waves_env);
+        const int64_t G = (n + per_wg - 1) / per_wg;
         ProfScope prof(PK_KDE1D_FWD, stream);
-        if (R == 4) {
-            MF_ALLOW_DYN_SMEM(proj_kde1d_fwd_kernel<4>, smem);
-            MF_LAUNCH(proj_kde1d_fwd_kernel<4>, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
-                      1.0f / sigma, R, Sfix);
-        } else {
-            MF_ALLOW_DYN_SMEM(proj_kde1d_fwd_kernel<0>, smem);
-            MF_LAUNCH(proj_kde1d_fwd_kernel<0>, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
-                      1.0f / sigma, R, Sfix);
-        }
+        bool launched = false;
+#define KDE1D_CASE(RTV, BL)                                                                                           \
+    if (!launched && (R == 4) == (RTV == 4) && block == BL) {                                                         \
+        MF_ALLOW_DYN_SMEM((proj_kde1d_fwd_kernel<RTV, BL>), smem);                                                    \
+        MF_LAUNCH((proj_kde1d_fwd_kernel<RTV, BL>), dim3((unsigned)G, ngroups), BL, smem, stream, x, n, d, V, P, Pg,   \
+                  coords, B, 1.0f / sigma, R, Sfix, per_wg);                                                          \
+        launched = true;                                                                                              \
+    }
+        KDE1D_CASE(4, 256) KDE1D_CASE(0, 256) KDE1D_CASE(4, 512) KDE1D_CASE(0, 512) KDE1D_CASE(4, 1024) KDE1D_CASE(0, 1024)
+#undef KDE1D_CASE
+        if (!launched) return fail("no 1-D KDE forward instance for block=%d (256, 512, 1024)", block);
         if (check_launch("mf_proj_kde1d_fwd")) return 1;
     }
     return fix_finish(Sfix, S, (int64_t)P * B, stream);
@@ -700,39 +893,42 @@ extern "C" int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* 
 extern "C" int mf_proj_kde1d_bwd(const float* x, int64_t n, int d, const float* V, int P, const float* coords, int B,
                                   float sigma, int radius, const float* gS, float* gx, int accumulate, void* stream) {
     if (kde_check(n, d, P, B)) return 1;
-    if (B > KDE_LDS_FLOATS) return fail("too many bins for the LDS image (%d)", B);
+    const size_t per_proj = sizeof(float) * ((size_t)B + KDE_VS);
+    if (per_proj + sizeof(float) * B > KDE_LDS_BYTES) return fail("too many bins for the LDS image (%d)", B);
     if (n == 0) return 0;
     const int R = radius < 0 ? 0 : (radius > B ? B : radius);
-    const int Pg = (KDE_LDS_FLOATS / B) < P ? (KDE_LDS_FLOATS / B) : P;
-    const size_t smem = sizeof(float) * ((size_t)Pg * B + (size_t)Pg * d + B);
+    static const int block_env = env_int("MENTFLOW_KDE1D_BWD_BLOCK", 0), lds_env = env_int("MENTFLOW_KDE1D_BWD_LDS", 0);
+    const int block = block_env ? block_env : (n >= 262144 ? 512 : 256);
+    size_t budget = lds_env ? (size_t)lds_env : (size_t)52 * 1024;
+    if (budget > KDE_LDS_BYTES) budget = KDE_LDS_BYTES;
+    int Pg = (int)((budget - sizeof(float) * B) / per_proj);
+    if (Pg < 1) Pg = 1;
+    if (Pg > P) Pg = P;
+    const size_t smem = per_proj * Pg + sizeof(float) * B;
     // lanes per particle: enough workgroups to give every SIMD a wave (>= 1024 workgroups of 4 waves), at most 8
     int CH = 1;
-    while (CH < 8 && CH * 2 <= P && (n * CH + KDE_BLOCK - 1) / KDE_BLOCK < 4 * NUM_CU) CH *= 2;
-    const int64_t G = (n * CH + KDE_BLOCK - 1) / KDE_BLOCK;
+    while (CH < 8 && CH * 2 <= P && (n * CH + block - 1) / block < 4 * NUM_CU) CH *= 2;
+    const int64_t G = (n * CH + block - 1) / block;
     ProfScope prof(PK_KDE1D_BWD, stream);
-    if (R == 4) {
-        MF_ALLOW_DYN_SMEM(proj_kde1d_bwd_kernel<4>, smem);
-        MF_LAUNCH(proj_kde1d_bwd_kernel<4>, dim3((unsigned)G), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
-                  1.0f / sigma, R, gS, gx, accumulate, CH);
-    } else {
-        MF_ALLOW_DYN_SMEM(proj_kde1d_bwd_kernel<0>, smem);
-        MF_LAUNCH(proj_kde1d_bwd_kernel<0>, dim3((unsigned)G), KDE_BLOCK, smem, stream, x, n, d, V, P, Pg, coords, B,
-                  1.0f / sigma, R, gS, gx, accumulate, CH);
+    bool launched = false;
+#define KDE1DB_CASE(RTV, BL)                                                                                          \
+    if (!launched && (R == 4) == (RTV == 4) && block == BL) {                                                         \
+        MF_ALLOW_DYN_SMEM((proj_kde1d_bwd_kernel<RTV, BL>), smem);                                                    \
+        MF_LAUNCH((proj_kde1d_bwd_kernel<RTV, BL>), dim3((unsigned)G), BL, smem, stream, x, n, d, V, P, Pg, coords, B,  \
+                  1.0f / sigma, R, gS, gx, accumulate, CH);                                                           \
+        launched = true;                                                                                              \
     }
+    KDE1DB_CASE(4, 256) KDE1DB_CASE(0, 256) KDE1DB_CASE(4, 512) KDE1DB_CASE(0, 512) KDE1DB_CASE(4, 1024) KDE1DB_CASE(0, 1024)
+#undef KDE1DB_CASE
+    if (!launched) return fail("no 1-D KDE backward instance for block=%d (256, 512, 1024)", block);
     return check_launch("mf_proj_kde1d_bwd");
 }
 
-static int kde2d_geometry(int d, int P, int Bx, int By, int rx, int ry, int* Pg, size_t* smem, int extra,
-                          int budget_floats = KDE_LDS_FLOATS) {
+static int kde2d_check(int d, int P, int Bx, int By, int rx, int ry, size_t entry_bytes) {
     if (rx > KDE_RMAX2D || ry > KDE_RMAX2D)
         return fail("2-D KDE kernel supports a truncation radius <= %d bins (bandwidth <= 0.6 bin widths)", KDE_RMAX2D);
-    const int BB = Bx * By;
-    if (BB > KDE_LDS_FLOATS) return fail("2-D histogram image %dx%d exceeds the LDS budget", Bx, By);
-    int g = budget_floats / BB;
-    if (g < 1) g = 1;
-    if (g > P) g = P;
-    *Pg = g;
-    *smem = sizeof(float) * ((size_t)g * BB + 2 * (size_t)g * d + Bx + By + extra);
+    if (entry_bytes * (size_t)Bx * By + sizeof(float) * (2 * KDE_VS + Bx + By) > KDE_LDS_BYTES)
+        return fail("2-D histogram image %dx%d exceeds the LDS budget", Bx, By);
     return 0;
 }
 
@@ -740,28 +936,40 @@ extern "C" int mf_proj_kde2d_fwd(const float* x, int64_t n, int d, const float* 
                                   const float* coords_x, int Bx, float sigma_x, int radius_x, const float* coords_y,
                                   int By, float sigma_y, int radius_y, float* S, void* ws, void* stream) {
     if (kde_check(n, d, P, Bx) || kde_check(n, d, P, By)) return 1;
-    if (radius_x > KDE_RMAX2D || radius_y > KDE_RMAX2D)
-        return fail("2-D KDE kernel supports a truncation radius <= %d bins (bandwidth <= 0.6 bin widths)", KDE_RMAX2D);
+    if (kde2d_check(d, P, Bx, By, radius_x, radius_y, sizeof(u64))) return 1;
     const int BB = Bx * By;
-    const int budget_max = 18432;                     // 144 KiB of 64-bit bins
-    if (BB > budget_max) return fail("2-D histogram image %dx%d exceeds the LDS budget", Bx, By);
-    // images per workgroup: ~72 KiB, so that two workgroups share a CU
-    static const int fwd_budget = [] { const char* e = getenv("MENTFLOW_KDE2D_FWD_BINS"); return e ? atoi(e) : 9216; }();
-    const int budget = fwd_budget > BB ? (fwd_budget > budget_max ? budget_max : fwd_budget) : BB;
-    double* Sfix = reinterpret_cast<double*>(ws);
-    if (hipMemsetAsync(Sfix, 0, sizeof(double) * (size_t)P * BB, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
+    u64* Sfix = reinterpret_cast<u64*>(ws);
+    if (hipMemsetAsync(Sfix, 0, 2 * sizeof(u64) * (size_t)P * BB, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
     if (n > 0) {
-        int Pg = budget / BB;
+        // tuned on MI355X at C5 (tools/kde_sweep.py): one 85 x 85 image (58 KiB) per 1024-thread workgroup, two
+        // workgroups per CU: 6.0 ms against 6.7 (512 threads) / 9-16 ms (256 threads, the r01 shape)
+        static const int lds_env = env_int("MENTFLOW_KDE2D_FWD_LDS", 60 * 1024), block_env = env_int("MENTFLOW_KDE2D_BLOCK", 1024);
+        static const int waves_env = env_int("MENTFLOW_KDE2D_WAVES", 4);
+        const size_t per_proj = sizeof(u64) * (size_t)BB + sizeof(float) * 2 * KDE_VS;
+        const size_t fixed = sizeof(float) * ((size_t)Bx + By);
+        size_t budget = (size_t)lds_env;
+        if (budget > KDE_LDS_BYTES) budget = KDE_LDS_BYTES;
+        if (budget < per_proj + fixed) budget = per_proj + fixed;
+        int Pg = (int)((budget - fixed) / per_proj);
         if (Pg > P) Pg = P;
-        const int ds = d | 1;
-        const size_t smem = sizeof(u64) * (size_t)Pg * BB + sizeof(float) * (2 * (size_t)Pg * ds + Bx + By);
+        const int block = block_env;
+        const size_t smem = per_proj * Pg + fixed;
         const int ngroups = (P + Pg - 1) / Pg;
-        int G = grid_for(n, KDE_BLOCK, (NUM_CU * 8 + ngroups - 1) / ngroups);   // >= 256 particles per workgroup
-        if ((n + G - 1) / G > KDE_MAX_PER_WG) G = (int)((n + KDE_MAX_PER_WG - 1) / KDE_MAX_PER_WG);
+        const int per_wg = kde_per_wg(n, ngroups, block, waves_env);
+        const int64_t G = (n + per_wg - 1) / per_wg;
+        const int RT = (radius_x == 4 && radius_y == 4) ? 4 : 0;
         ProfScope prof(PK_KDE2D_FWD, stream);
-        MF_ALLOW_DYN_SMEM(proj_kde2d_fwd_kernel, smem);
-        MF_LAUNCH(proj_kde2d_fwd_kernel, dim3(G, ngroups), KDE_BLOCK, smem, stream, x, n, d, V0, V1, P, Pg, coords_x, Bx,
-                  1.0f / sigma_x, radius_x, coords_y, By, 1.0f / sigma_y, radius_y, Sfix);
+        bool launched = false;
+#define KDE2D_CASE(RTV, BL)                                                                                           \
+    if (!launched && RT == RTV && block == BL) {                                                                      \
+        MF_ALLOW_DYN_SMEM((proj_kde2d_fwd_kernel<RTV, BL>), smem);                                                    \
+        MF_LAUNCH((proj_kde2d_fwd_kernel<RTV, BL>), dim3((unsigned)G, ngroups), BL, smem, stream, x, n, d, V0, V1, P,  \
+                  Pg, coords_x, Bx, 1.0f / sigma_x, radius_x, coords_y, By, 1.0f / sigma_y, radius_y, Sfix, per_wg);   \
+        launched = true;                                                                                              \
+    }
+        KDE2D_CASE(4, 256) KDE2D_CASE(0, 256) KDE2D_CASE(4, 512) KDE2D_CASE(0, 512) KDE2D_CASE(4, 1024) KDE2D_CASE(0, 1024)
+#undef KDE2D_CASE
+        if (!launched) return fail("no 2-D KDE forward instance for block=%d (256, 512, 1024)", block);
         if (check_launch("mf_proj_kde2d_fwd")) return 1;
     }
     return fix_finish(Sfix, S, (int64_t)P * BB, stream);
@@ -772,19 +980,66 @@ extern "C" int mf_proj_kde2d_bwd(const float* x, int64_t n, int d, const float* 
                                   int By, float sigma_y, int radius_y, const float* gS, float* gx, int accumulate,
                                   void* stream) {
     if (kde_check(n, d, P, Bx) || kde_check(n, d, P, By)) return 1;
-    int Pg;
-    size_t smem;
-    // ~40 KB of images per workgroup: four workgroups per CU (see the kernel's header comment)
-    static const int bwd_budget = [] { const char* e = getenv("MENTFLOW_KDE2D_BWD_FLOATS"); return e ? atoi(e) : 10240; }();
-    if (kde2d_geometry(d, P, Bx, By, radius_x, radius_y, &Pg, &smem, 0, bwd_budget)) return 1;
+    if (kde2d_check(d, P, Bx, By, radius_x, radius_y, sizeof(float))) return 1;
     if (n == 0) return 0;
-    const int64_t per_wg = (int64_t)KDE_BLOCK * KDE2D_BWD_NPT;
+    const int BB = Bx * By;
+    // tuned on MI355X at C5 (tools/kde_sweep.py): 1024 threads x 4 particles each with four 85 x 85 images (116 KiB)
+    // staged per pass — 3.8 ms against 5.3 ms for the r01 shape (256 threads x 4, one image); staging an image costs
+    // L2 -> LDS traffic per workgroup, so fat workgroups win once there are enough particles to fill the chip with them.
+    // Smaller batches step down to (1024, 2), (1024, 1), (512, 1), (256, 1) until >= 2 workgroups per CU exist.
+    static const int lds_env = env_int("MENTFLOW_KDE2D_BWD_LDS", 0), block_env = env_int("MENTFLOW_KDE2D_BWD_BLOCK", 0);
+    static const int npt_env = env_int("MENTFLOW_KDE2D_BWD_NPT", 0);
+    int block_h = 256, npt_h = 1;
+    {
+        static const int shapes[5][2] = {{1024, 4}, {1024, 2}, {1024, 1}, {512, 1}, {256, 1}};
+        for (int k = 0; k < 5; ++k) {
+            block_h = shapes[k][0];
+            npt_h = shapes[k][1];
+            if (n / ((int64_t)block_h * npt_h) >= 2 * NUM_CU) break;
+        }
+    }
+    const size_t per_proj = sizeof(float) * ((size_t)BB + 2 * KDE_VS);
+    const size_t fixed = sizeof(float) * ((size_t)Bx + By);
+    const int block = block_env ? block_env : block_h, npt = npt_env ? npt_env : npt_h;
+    size_t budget = lds_env ? (size_t)lds_env : (block >= 1024 ? (size_t)118 * 1024 : (block >= 512 ? (size_t)59 * 1024 : (size_t)30 * 1024));
+    if (budget > KDE_LDS_BYTES) budget = KDE_LDS_BYTES;
+    if (budget < per_proj + fixed) budget = per_proj + fixed;
+    int Pg = (int)((budget - fixed) / per_proj);
+    if (Pg > P) Pg = P;
+    const size_t smem = per_proj * Pg + fixed;
+    const int64_t per_wg = (int64_t)block * npt;
     const int64_t G = (n + per_wg - 1) / per_wg;
+    const int RT = (radius_x == 4 && radius_y == 4) ? 4 : 0;
     ProfScope prof(PK_KDE2D_BWD, stream);
-    MF_ALLOW_DYN_SMEM(proj_kde2d_bwd_kernel, smem);
-    MF_LAUNCH(proj_kde2d_bwd_kernel, dim3((unsigned)G), KDE_BLOCK, smem, stream, x, n, d, V0, V1, P, Pg, coords_x, Bx,
-              1.0f / sigma_x, radius_x, coords_y, By, 1.0f / sigma_y, radius_y, gS, gx, accumulate);
+    bool launched = false;
+#define KDE2DB_CASE(RTV, BL, NP)                                                                                      \
+    if (!launched && RT == RTV && block == BL && npt == NP) {                                                         \
+        MF_ALLOW_DYN_SMEM((proj_kde2d_bwd_kernel<RTV, BL, NP>), smem);                                                \
+        MF_LAUNCH((proj_kde2d_bwd_kernel<RTV, BL, NP>), dim3((unsigned)G), BL, smem, stream, x, n, d, V0, V1, P, Pg,   \
+                  coords_x, Bx, 1.0f / sigma_x, radius_x, coords_y, By, 1.0f / sigma_y, radius_y, gS, gx, accumulate); \
+        launched = true;                                                                                              \
+    }
+#define KDE2DB_CASES(BL, NP) KDE2DB_CASE(4, BL, NP) KDE2DB_CASE(0, BL, NP)
+    KDE2DB_CASES(256, 1) KDE2DB_CASES(256, 2) KDE2DB_CASES(256, 4) KDE2DB_CASES(512, 1) KDE2DB_CASES(512, 2) KDE2DB_CASES(512, 4)
+    KDE2DB_CASES(1024, 1) KDE2DB_CASES(1024, 2) KDE2DB_CASES(1024, 4)
+#undef KDE2DB_CASES
+#undef KDE2DB_CASE
+    if (!launched) return fail("no 2-D KDE backward instance for block=%d npt=%d", block, npt);
     return check_launch("mf_proj_kde2d_bwd");
+}
+
+// geometry of the hard-binned 2-D counts kernel: as many int images as fit the budget
+static int kde2d_geometry(int d, int P, int Bx, int By, int rx, int ry, int* Pg, size_t* smem, int extra,
+                          int budget_floats = KDE_LDS_FLOATS) {
+    (void)rx; (void)ry;
+    const int BB = Bx * By;
+    if (BB > KDE_LDS_FLOATS) return fail("2-D histogram image %dx%d exceeds the LDS budget", Bx, By);
+    int g = budget_floats / BB;
+    if (g < 1) g = 1;
+    if (g > P) g = P;
+    *Pg = g;
+    *smem = sizeof(float) * ((size_t)g * BB + 2 * (size_t)g * d + Bx + By + extra);
+    return 0;
 }
 
 extern "C" int mf_proj_hist1d_counts(const float* x, int64_t n, int d, const float* V, int P, const float* edges, int B,

@@ -208,7 +208,7 @@ class ProjKde1dFn(torch.autograd.Function):
         x, V, coords = _f32c(x), _f32c(V), _f32c(coords)
         P, B = V.shape[0], coords.numel()
         S = torch.empty(P, B, dtype=_F32, device=x.device)
-        ws = torch.empty(P * B, dtype=torch.int64, device=x.device)
+        ws = torch.empty(_lib.get_lib().mf_proj_kde_ws_bytes(P, B) // 8, dtype=torch.int64, device=x.device)
         call("mf_proj_kde1d_fwd", ptr(x), x.shape[0], x.shape[1], ptr(V), P, ptr(coords), B, float(sigma), int(radius),
              ptr(S), ptr(ws), stream_ptr(x))
         ctx.save_for_backward(x, V, coords)
@@ -232,7 +232,7 @@ class ProjKde2dFn(torch.autograd.Function):
         x, V0, V1, cx, cy = _f32c(x), _f32c(V0), _f32c(V1), _f32c(coords_x), _f32c(coords_y)
         P, Bx, By = V0.shape[0], cx.numel(), cy.numel()
         S = torch.empty(P, Bx, By, dtype=_F32, device=x.device)
-        ws = torch.empty(P * Bx * By, dtype=torch.int64, device=x.device)
+        ws = torch.empty(_lib.get_lib().mf_proj_kde_ws_bytes(P, Bx * By) // 8, dtype=torch.int64, device=x.device)
         call("mf_proj_kde2d_fwd", ptr(x), x.shape[0], x.shape[1], ptr(V0), ptr(V1), P, ptr(cx), Bx, float(sigma_x),
              int(radius_x), ptr(cy), By, float(sigma_y), int(radius_y), ptr(S), ptr(ws), stream_ptr(x))
         ctx.save_for_backward(x, V0, V1, cx, cy)
