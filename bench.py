@@ -84,6 +84,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--bwd-chunk", type=int, default=None, help="particles per flow-backward chunk (tuning)")
     ap.add_argument("--meas-samples", type=int, default=1_000_000, help="ground-truth samples behind the measurements")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a hipGraph (mentflow_amd.graph.GraphedTrainStep): the launch-bound small-batch "
+                         "regime, e.g. --per-gpu 25000; single GPU only")
     # test infrastructure only: run the ranks on the host-emulated kernel build (tests/emu) so that the launcher and the
     # multi-rank plumbing can be exercised in a GPU-less container.  The line it prints is marked as emulated.
     ap.add_argument("--test-emulator-lib", default=None, help=argparse.SUPPRESS)
@@ -290,8 +293,10 @@ def run_worker(args) -> int:
         per_gpu, global_batch = weak_per_gpu, weak_per_gpu * world
     prob = build_problem(device=device, penalty_parameter=500.0, meas_samples=args.meas_samples, **w)  # same seed: same weights
     model = prob.model
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0)   # experiments/setup.py:166-170
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0, capturable=bool(args.graph))   # experiments/setup.py:166-170
     torch.manual_seed(1234 + rank)                                           # every rank draws its own particles
+    if args.graph and (world > 1 or emulated):
+        raise SystemExit("--graph is a single-GPU mode")
     if args.bwd_chunk:
         model.generator.spec().bwd_chunk = args.bwd_chunk
 
@@ -299,12 +304,18 @@ def run_worker(args) -> int:
         if device.type == "cuda":
             torch.cuda.synchronize()
 
-    def step():
-        opt.zero_grad()
-        L, H, D = model.loss(global_batch)
-        L.backward()
-        opt.step()
-        return L
+    if args.graph:
+        gstep = mf.graph.GraphedTrainStep(model, opt, global_batch)
+
+        def step():
+            return gstep.step()[0]
+    else:
+        def step():
+            opt.zero_grad()
+            L, H, D = model.loss(global_batch)
+            L.backward()
+            opt.step()
+            return L
 
     # evidence that the collective really spans the ranks: all-reduce of ones over the production backend
     ranks_seen = 1
@@ -362,7 +373,8 @@ def run_worker(args) -> int:
                               "max_ms_per_step": max(region_s) / args.steps * 1e3},
             "config": {"workload": f"{args.workload}: {desc}", "global_batch": global_batch, "per_gpu_batch": per_gpu,
                        "parallelism": f"dp{world} (particle batch sharded; 2 all-reduces/step)",
-                       "step": "zero_grad + MENTFlow.loss + backward + AdamW.step", "final_loss": final_loss},
+                       "step": "zero_grad + MENTFlow.loss + backward + AdamW.step" + (" (hipGraph replay)" if args.graph else ""),
+                       "final_loss": final_loss},
         }
         kernels = {k: v for k, v in prof.items() if v[1] > 0}
         if kernels:

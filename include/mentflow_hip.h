@@ -112,8 +112,9 @@ int mf_flow_affine_layer_inv(const float* image, int d, int hidden_layers, const
  * Only the 2*radius+1 bins around each projected particle are visited (dropped kernel values are below
  * exp(-(radius+1/2)^2 delta^2 / (2 sigma^2)), 3e-18 for the reference's sigma = delta/2 and radius 4); pass
  * radius >= B for the dense sum.                                                                              */
-/* ws: mf_proj_kde_ws_bytes(P, bins) bytes of scratch (fp64 accumulators of the per-workgroup sums; inside a
- * workgroup weights are summed as 2^-50 fixed-point integers with 64-bit LDS atomics).                          */
+/* ws: mf_proj_kde_ws_bytes(P, bins) bytes of scratch: one [lo | hi] pair of 64-bit INTEGER accumulators per bin.
+ * Weights are summed as 2^-50 fixed-point integers at every level (64-bit LDS atomics inside a workgroup, 64-bit
+ * integer global atomics of the low / high halves across workgroups): exact, order independent, bitwise reproducible. */
 int64_t mf_proj_kde_ws_bytes(int P, int bins);
 int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* V, int P, const float* coords, int B,
                       float sigma, int radius, float* S, void* ws, void* stream);

@@ -1004,7 +1004,15 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         // one feature: phi_i, spline forward + adjoint, stage gphi_i, this wave's share of dW3_i, gh += W3_i^T gphi_i
         auto feature = [&](int i, f32x16_t& accF, float& bsF) {
             float v[32], gv[32];
-            const int nc = fb_blk_cols(sp, i);
+            // per-feature mask bounds by scalar selects over values held in SGPRs: indexing the kernel-argument struct
+            // with the run-time feature index costs an exposed scalar-memory round trip per use (three per feature)
+            int kend3_i = sp.kend3[0], rt1_i = sp.rt1[0];
+#pragma unroll
+            for (int j = 1; j < FB_DMAX; ++j) {
+                kend3_i = (i == j) ? sp.kend3[j] : kend3_i;
+                rt1_i = (i == j) ? sp.rt1[j] : rt1_i;
+            }
+            const int nc = 2 * ((kend3_i + 3) & ~3);
             const float* W3 = lds + w3off;                 // T_i[c][m]
             w3off += nc * WS;
             t0_ = WS_T();
@@ -1013,7 +1021,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     phi[rt] = bias_tile(lds + offB3c + i * HID, rt, hh);
-                    chain64_upto<WS>(phi[rt], W3 + 4 * hh * WS + 32 * rt + col, (sp.kend3[i] + 3) >> 2, BTile{h[L - 1]});
+                    chain64_upto<WS>(phi[rt], W3 + 4 * hh * WS + 32 * rt + col, (kend3_i + 3) >> 2, BTile{h[L - 1]});
                 }
 #pragma unroll
                 for (int m = 0; m < 32; ++m) v[m] = phi[m >> 4][m & 15];
@@ -1037,28 +1045,29 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             t0_ = WS_T();
             stage_tile(myA, sl, gv);
             WS_ACC(c_[4], t0_);
-            t0_ = WS_T();
-            __syncthreads();
-            WS_ACC(c_[5], t0_);
-            t0_ = WS_T();
-            {
-                const bool full = sp.rt1[i] != 0;
-                const int ra = full ? fra : hra, rb = full ? frb : 0;
-                const int t0 = full ? 0 : ht0, t1 = full ? 2 : 1;
-                const bool mm = sp.kend3[i] > 0;
-                dw_accum(SA, SB, ra, rb, t0, t1, mm, full ? frb : -1, lane, accF, bsF);
-                WS_ACC(c_[6], t0_);
-                t0_ = WS_T();
-            }
+            // gh += W3_i^T gphi_i BEFORE the meeting point of the product: the chain gives the four waves ~3 k cycles of
+            // slack at barrier B, and gphi (32 registers) is dead by the time the product's fragments are live
             t0_ = WS_T();
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                if (rt ? sp.rt1[i] != 0 : sp.kend3[i] > 0) {       // hidden tile rt receives something from block i
+                if (rt ? rt1_i != 0 : kend3_i > 0) {               // hidden tile rt receives something from block i
                     const int c = 32 * rt + col;
                     chain64<1>(gh[rt], (c < nc ? W3 + c * WS : zrow) + 4 * hh, 0, 8, BVec{gv});
                 }
             }
             WS_ACC(c_[8], t0_);
+            t0_ = WS_T();
+            __syncthreads();
+            WS_ACC(c_[5], t0_);
+            t0_ = WS_T();
+            {
+                const bool full = rt1_i != 0;
+                const int ra = full ? fra : hra, rb = full ? frb : 0;
+                const int t0 = full ? 0 : ht0, t1 = full ? 2 : 1;
+                const bool mm = kend3_i > 0;
+                dw_accum(SA, SB, ra, rb, t0, t1, mm, full ? frb : -1, lane, accF, bsF);
+                WS_ACC(c_[6], t0_);
+            }
         };
         // The feature loop stays rolled (the spline is ~8 KB of code), so the accumulator of "the current feature"
         // cannot be indexed by i: two features per iteration use accO[0] and accO[1], then the array is rotated by two
@@ -1812,13 +1821,13 @@ extern "C" int64_t mf_flow_image_floats(int d, int hidden_layers) { return image
 
 // Does mf_flow_rqs_layer_bwd take the fused kernel (parameter gradients inside the backward kernel, no scratch) for
 // this call?  It needs the mask structure (order) for the compact last-layer image, d <= FB_DMAX accumulator blocks and
-// an LDS budget that fits; small batches (<= 1024 tiles: at most one 4-tile group per workgroup) keep the two-kernel
-// path, whose per-workgroup set-up is lighter (0.54 vs 0.66 ms at 25 000 particles).  MENTFLOW_BWD_FUSED=0 / 1
-// forces the choice where both are possible.
+// an LDS budget that fits.  Since the deterministic slab flush replaced the contended float atomics the fused kernel also
+// wins at small batches (25 000 particles, C4 step: 1.21 ms against 1.68 ms for the two-kernel path, profiles/r02), so
+// it is the default for every batch size; MENTFLOW_BWD_FUSED=0 forces the two-kernel path (tests), =1 is the default.
 static bool rqs_bwd_fused(int64_t n, int d, int hidden_layers, const int32_t* order, const Sparsity& sp, size_t* smem) {
     const char* e = getenv("MENTFLOW_BWD_FUSED");
     if ((e && atoi(e) == 0) || order == nullptr || d > FB_DMAX) return false;
-    if (!(e && atoi(e) == 1) && (n + 31) / 32 <= 4 * NUM_CU) return false;
+    (void)n;
     size_t fl = image_layout(d, hidden_layers, d).offW3;
     for (int i = 0; i < d; ++i) fl += (size_t)WS * (2 * ((sp.kend3[i] + 3) & ~3));
     fl += (size_t)d * HID + HID;
@@ -1962,12 +1971,12 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
 // ------------------------------------------------------------------------------------------------ affine C ABI
 extern "C" int64_t mf_flow_affine_image_floats(int d, int hidden_layers) { return image_layout(d, hidden_layers, 1).total; }
 
-// the fused affine backward needs no mask structure (dense image, 117 KB of LDS for every d <= 7); same batch-size
-// threshold and MENTFLOW_BWD_FUSED override as the spline layers
+// the fused affine backward needs no mask structure (dense image, 117 KB of LDS for every d <= 7); default for every
+// batch size, MENTFLOW_BWD_FUSED=0 forces the two-kernel path
 static bool affine_bwd_fused(int64_t n) {
+    (void)n;
     const char* e = getenv("MENTFLOW_BWD_FUSED");
-    if (e && atoi(e) == 0) return false;
-    return (e && atoi(e) == 1) || (n + 31) / 32 > 4 * NUM_CU;
+    return !(e && atoi(e) == 0);
 }
 
 extern "C" int64_t mf_flow_affine_bwd_scratch_floats(int64_t n, int hidden_layers) {

@@ -3,7 +3,13 @@ AdamW inner loop, NaN guard, best-state tracking) without the plotting/pickle si
 
 Differences, all on the host side: the per-iteration scalars (L, H, mean D) are fetched with ONE device->host copy
 instead of the reference's six synchronising conversions per iteration (train.py:167-214), and the history is kept in
-memory (``self.history``) instead of being re-pickled every iteration (utils/logging.py:64-66)."""
+memory (``self.history``) instead of being re-pickled every iteration (utils/logging.py:64-66).
+
+``graphed=True`` replays the whole iteration (zero_grad + loss + backward + optimizer step) from a hipGraph captured
+once per epoch (the penalty parameter is a capture-time constant; the learning rate too: a scheduler change triggers a
+re-capture) — the launch-bound small-batch regime of the reference (25 000 particles).  Needs a capturable optimizer
+(``torch.optim.AdamW(..., capturable=True)``).  A non-finite loss is handled as the reference does: that iteration's
+update is undone (mentflow_amd.graph.GraphedTrainStep.undo_last_step)."""
 from __future__ import annotations
 
 import copy
@@ -15,7 +21,8 @@ import torch
 
 class Trainer:
     def __init__(self, model, optimizer, lr_scheduler=None, plot: Optional[Callable] = None, eval: Optional[Callable] = None,
-                 output_dir: Optional[str] = None, notebook: bool = False, load_best: bool = True, verbose: bool = True) -> None:
+                 output_dir: Optional[str] = None, notebook: bool = False, load_best: bool = True, verbose: bool = True,
+                 graphed: bool = False) -> None:
         self.model = model
         self.optimizer = optimizer
         self.lr_scheduler = lr_scheduler
@@ -24,6 +31,7 @@ class Trainer:
         self.output_dir = output_dir
         self.load_best = load_best
         self.verbose = verbose
+        self.graphed = graphed
         self.history: Dict[str, List] = {}
 
     def _log(self, info: dict) -> None:
@@ -44,15 +52,29 @@ class Trainer:
         def train_epoch(epoch):
             best_loss = float("inf")
             best_state_dict = copy.deepcopy(model.state_dict())
+            gstep = None
+            if self.graphed:
+                from .graph import GraphedTrainStep
+                gstep = GraphedTrainStep(model, self.optimizer, batch_size, guard=True)
+                lr_captured = [g["lr"] for g in self.optimizer.param_groups]
             for iteration in range(iterations):
-                self.optimizer.zero_grad()
-                loss, H, D = model.loss(batch_size)
-                scalars = torch.stack([loss.detach(), H.detach() if torch.is_tensor(H) else torch.tensor(float(H), device=loss.device),
-                                       torch.stack([d.detach() for d in D]).mean()]).cpu()     # one sync
-                L_val, H_val, D_val = (float(v) for v in scalars)
-                if not (L_val != L_val or L_val in (float("inf"), float("-inf"))):              # train.py:167
-                    loss.backward()
-                    self.optimizer.step()
+                if gstep is not None:
+                    if [g["lr"] for g in self.optimizer.param_groups] != lr_captured:      # the scheduler moved the rate
+                        gstep.recapture()
+                        lr_captured = [g["lr"] for g in self.optimizer.param_groups]
+                    gstep.step()
+                    L_val, H_val, D_val = (float(v) for v in gstep.scalars().cpu())         # one sync
+                    if L_val != L_val or L_val in (float("inf"), float("-inf")):            # train.py:167
+                        gstep.undo_last_step()
+                else:
+                    self.optimizer.zero_grad()
+                    loss, H, D = model.loss(batch_size)
+                    scalars = torch.stack([loss.detach(), H.detach() if torch.is_tensor(H) else torch.tensor(float(H), device=loss.device),
+                                           torch.stack([d.detach() for d in D]).mean()]).cpu()     # one sync
+                    L_val, H_val, D_val = (float(v) for v in scalars)
+                    if not (L_val != L_val or L_val in (float("inf"), float("-inf"))):              # train.py:167
+                        loss.backward()
+                        self.optimizer.step()
                 self._log(dict(epoch=epoch, iteration=iteration, L=L_val, H=H_val, D_norm=D_val, batch_size=batch_size,
                                learning_rate=self.optimizer.param_groups[0]["lr"], penalty=model.penalty_parameter,
                                time=time.time() - start_time))

@@ -1,6 +1,9 @@
 // TEST INFRASTRUCTURE — fiber scheduler for tests/emu/hip_emu.h (see the header for scope).
 #include "hip_emu.h"
 
+#include <sys/mman.h>
+#include <unistd.h>
+
 namespace emu {
 
 BlockState* g_block = nullptr;
@@ -8,10 +11,41 @@ dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
 static void fiber_entry() {
     BlockState* b = g_block;
+    MF_FIBER_FINISH(nullptr, &b->sched_bottom, &b->sched_size);      // first entry: learn the scheduler's stack
     b->body();
     b->fibers[b->cur].done = true;
+    MF_FIBER_START(nullptr, b->sched_bottom, b->sched_size);         // this fiber never runs again
     swapcontext(&b->fibers[b->cur].ctx, &b->sched);
 }
+
+// Guard-paged dynamic LDS: [ PROT_NONE page | slack ... block (size bytes, 64-byte aligned start) | PROT_NONE page ]
+struct GuardedLds {
+    char* map = nullptr;
+    size_t map_bytes = 0;
+    char* block = nullptr;
+    GuardedLds(size_t size) {
+        const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+        const size_t body = ((size + 63) / 64 * 64 + page - 1) / page * page;
+        map_bytes = body + 2 * page;
+        map = (char*)mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (map == MAP_FAILED) { perror("emu: mmap"); abort(); }
+        mprotect(map, page, PROT_NONE);
+        mprotect(map + page + body, page, PROT_NONE);
+        // the kernels' MF_DYN_SMEM rounds the pointer UP to 64 bytes: choose a start that is already aligned and whose
+        // end is within 63 bytes of the upper guard page (sizes are multiples of 4, images mostly of 64)
+        block = map + page + body - (size + 63) / 64 * 64;
+#ifdef MF_EMU_ASAN
+        __asan_poison_memory_region(map + page, (size_t)(block - (map + page)));
+        __asan_poison_memory_region(block + size, (size_t)((map + page + body) - (block + size)));
+#endif
+    }
+    ~GuardedLds() {
+#ifdef MF_EMU_ASAN
+        __asan_unpoison_memory_region(map, map_bytes);
+#endif
+        munmap(map, map_bytes);
+    }
+};
 
 void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
     const int nthreads = (int)(block.x * block.y * block.z);
@@ -20,8 +54,8 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
     bs.fibers.resize(nthreads);
     bs.waves.resize((nthreads + WAVE - 1) / WAVE);
     for (auto& f : bs.fibers) f.stack = (char*)malloc(STACK);
-    std::vector<char> dyn(smem + 64);
-    bs.dyn_smem = dyn.data();
+    GuardedLds dyn(smem);
+    bs.dyn_smem = dyn.block;
     BlockState* prev = g_block;
     g_block = &bs;
     g_blockDim = block;
@@ -54,7 +88,9 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
                         if (f.done) continue;
                         bs.cur = i;
                         g_threadIdx = f.tid;
+                        MF_FIBER_START(&bs.sched_fake_stack, f.stack, STACK);
                         swapcontext(&bs.sched, &f.ctx);
+                        MF_FIBER_FINISH(bs.sched_fake_stack, nullptr, nullptr);
                         if (f.done) { --remaining; ++progressed; }
                     }
                     if (++spins > 200000000L) { fprintf(stderr, "emu: deadlock (divergent collective?)\n"); abort(); }

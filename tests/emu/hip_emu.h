@@ -62,11 +62,30 @@ namespace emu {
 constexpr int WAVE = 64;
 constexpr size_t STACK = 512 * 1024;
 
+// AddressSanitizer has to be told about every stack switch of the fibers (tests/emu/build_sanitize.sh)
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define MF_EMU_ASAN 1
+#endif
+#endif
+#ifdef MF_EMU_ASAN
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+extern "C" void __asan_poison_memory_region(void const volatile* addr, size_t size);
+extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
+#define MF_FIBER_START(save, bottom, size) __sanitizer_start_switch_fiber(save, bottom, size)
+#define MF_FIBER_FINISH(save, bottom_old, size_old) __sanitizer_finish_switch_fiber(save, bottom_old, size_old)
+#else
+#define MF_FIBER_START(save, bottom, size) ((void)0)
+#define MF_FIBER_FINISH(save, bottom_old, size_old) ((void)0)
+#endif
+
 struct Fiber {
     ucontext_t ctx;
     char* stack = nullptr;
     bool done = false;
     dim3 tid;
+    void* fake_stack = nullptr;      // ASan fake-stack handle while this fiber is switched out
 };
 
 struct WaveState {
@@ -84,7 +103,12 @@ struct BlockState {
     unsigned barrier_gen = 0;
     ucontext_t sched;
     std::function<void()> body;
+    // dynamic LDS of the workgroup: EXACTLY the requested size, its end on a PROT_NONE guard page (and, under ASan,
+    // the alignment slack in front of it poisoned): an out-of-range LDS index in a kernel faults on the CPU
     char* dyn_smem = nullptr;
+    void* sched_fake_stack = nullptr;
+    const void* sched_bottom = nullptr;
+    size_t sched_size = 0;
 };
 
 extern BlockState* g_block;
@@ -92,7 +116,10 @@ extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
 inline void yield() {
     BlockState* b = g_block;
-    swapcontext(&b->fibers[b->cur].ctx, &b->sched);
+    Fiber& f = b->fibers[b->cur];
+    MF_FIBER_START(&f.fake_stack, b->sched_bottom, b->sched_size);
+    swapcontext(&f.ctx, &b->sched);
+    MF_FIBER_FINISH(f.fake_stack, nullptr, nullptr);
 }
 
 inline int linear_tid() { return g_threadIdx.x + g_blockDim.x * (g_threadIdx.y + g_blockDim.y * g_threadIdx.z); }

@@ -213,7 +213,7 @@ def test_nn_generator_train_step_matches_oracle(backend):
 @pytest.mark.parametrize("d", [2, 6, 7])
 def test_maf_affine_forward_backward_match_oracle(backend, d, variant, monkeypatch):
     """BASELINE config C1's "affine coupling" flow: zuko MAF (MonotonicAffineTransform); both backward variants
-    (affine_layer_bwd_kernel + outer_accum, and affine_layer_bwd_fused_kernel, the default above 32 768 particles)."""
+    (affine_layer_bwd_kernel + outer_accum, and affine_layer_bwd_fused_kernel, the default)."""
     monkeypatch.setenv("MENTFLOW_BWD_FUSED", "1" if variant == "fused" else "0")
     gen = make_generator(backend, d, kind="maf", transforms=3)
     assert sum(p.numel() for p in gen.parameters()) == 3 * (64 * d + 64 + 2 * (64 * 64 + 64) + 2 * d * 64 + 2 * d)

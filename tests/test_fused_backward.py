@@ -1,6 +1,5 @@
-"""The fused backward (parameter gradients inside the backward kernel, hand-scheduled MFMA chains — the default for
-batches above 32 768 particles) against the two-kernel backward on identical inputs, on the GPU, at sizes where the
-fused kernel is the one the library picks.  Both are fp32 with different summation orders (and float atomics):
+"""The fused backward (parameter gradients inside the backward kernel, hand-scheduled MFMA chains — the default) against the two-kernel backward on identical inputs, on the GPU, at sizes where the
+fused kernel is the one the library picks.  Both are fp32 with different summation orders:
 agreement to 2e-5 of the largest gradient entry is required, ~5e-7 is typical.  The emulator runs of
 test_flow_kernels.py cover the same kernel's indexing against the oracle; this test covers what the emulator cannot
 see — the inline-asm scheduling (LDS prefetch distances, MFMA -> VALU read padding) on real hardware."""

@@ -12,8 +12,9 @@ from mentflow_amd.harness import build_problem
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n", [25_000, 40_000])       # two-kernel backward / fused backward (> 32 768 particles)
-def test_graphed_step_equals_eager_and_trains(n):
+@pytest.mark.parametrize("n,fused", [(25_000, "0"), (25_000, "1"), (40_000, "1")])   # two-kernel / fused backward
+def test_graphed_step_equals_eager_and_trains(n, fused, monkeypatch):
+    monkeypatch.setenv("MENTFLOW_BWD_FUSED", fused)
     from mentflow_amd import _lib
     _lib.use_library(_lib.DEFAULT_PATH)
     dev = torch.device("cuda", 0)
@@ -29,30 +30,30 @@ def test_graphed_step_equals_eager_and_trains(n):
         model.generator.inject_z = z
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0, capturable=True)
         if graphed:
-            # 3 eager warm-up steps (they also create the optimizer state, which must exist before capture), then
-            # the capture itself performs no step
+            # the 3 eager warm-up steps that graph capture needs are undone by GraphedTrainStep (parameters and AdamW
+            # state restored in place): the 3 replays are training steps 1-3, exactly like the 3 eager steps
             g = mf.graph.GraphedTrainStep(model, opt, n, warmup=3)
             outs = [tuple(t.clone() for t in g.step()) for _ in range(3)]
         else:
             outs = []
-            for it in range(6):
+            for it in range(3):
                 opt.zero_grad(set_to_none=False)
                 L, H, D = model.loss(n)
                 L.backward()
                 opt.step()
                 outs.append((L.detach().clone(), H.detach().clone(), torch.stack(D).detach().mean()))
-            outs = outs[3:]
         params = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
         return outs, params
 
     eager, pe = run(False)
     graphed, pg = run(True)
+    # every kernel on the path is deterministic (fixed-point histograms with integer flushes, slab-reduced parameter
+    # gradients: no float atomics anywhere): a replayed step reproduces the eager step BIT FOR BIT, and so do the
+    # parameters after 3 AdamW steps
     for a, b in zip(eager, graphed):
         for u, v in zip(a, b):
-            torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-6)
-    # parameters after 6 AdamW steps: float-atomic summation order in the gradient kernel differs run to run and Adam's
-    # g / sqrt(v) amplifies it for tiny gradients; 1e-4 is 2 % of the 6e-3 a parameter can move in 6 steps at lr 1e-3
-    torch.testing.assert_close(pe, pg, rtol=1e-3, atol=1e-4)
+            assert torch.equal(u, v), (u, v)
+    assert torch.equal(pe, pg), float((pe - pg).abs().max())
     # fresh particles per replay + speed at the reference batch size
     model.generator.inject_z = None
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0, capturable=True)
@@ -70,3 +71,39 @@ def test_graphed_step_equals_eager_and_trains(n):
     torch.cuda.synchronize(); t_eager = (time.perf_counter() - t0) / 50
     print(f"\n{n}-particle step: eager {t_eager*1e3:.2f} ms, graph replay {t_graph*1e3:.2f} ms")
     assert t_graph < 1.5 * t_eager          # at 25 k particles the step is GPU-bound (~1.9 ms), replay only removes host time
+
+
+def test_graphed_trainer_matches_eager_trainer_and_undo():
+    """Trainer(graphed=True): the penalty-method loop replayed from a per-epoch hipGraph must log the same (L, H, D)
+    history as the eager Trainer on an injected base draw (bitwise: every kernel is deterministic), across a penalty
+    update; GraphedTrainStep.undo_last_step restores parameters and optimizer state exactly."""
+    from mentflow_amd import _lib
+    _lib.use_library(_lib.DEFAULT_PATH)
+    dev = torch.device("cuda", 0)
+    n = 25_000
+    hist = {}
+    finals = {}
+    for graphed in (False, True):
+        prob = build_problem(ndim=6, num=25, bins=64, xmax=4.0, seed=2, transforms=5, prior_scale=1.0, device=dev,
+                             dist_name="rings", meas_samples=100_000)
+        model = prob.model
+        torch.manual_seed(0)
+        model.generator.inject_z = torch.randn(n, 6, device=dev)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0, capturable=True)
+        tr = mf.train.Trainer(model, opt, None, verbose=False, graphed=graphed)
+        tr.train(epochs=2, iterations=4, batch_size=n, rtol=-1, atol=-1, dmax=1e-12, penalty_start=10.0, penalty_step=20.0,
+                 penalty_scale=1.5, eval_batch_size=n)
+        hist[graphed] = tr.history
+        finals[graphed] = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    for key in ("L", "H", "D_norm", "penalty"):
+        assert hist[False][key] == hist[True][key], key
+    assert torch.equal(finals[False], finals[True])
+
+    # undo: one replay, then back to exactly the previous parameters / AdamW state
+    g = mf.graph.GraphedTrainStep(model, opt, n, guard=True)
+    before = [t.clone() for t in g._state]
+    g.step()
+    torch.cuda.synchronize()
+    assert any(not torch.equal(a, b) for a, b in zip(before, g._state))
+    g.undo_last_step()
+    assert all(torch.equal(a, b) for a, b in zip(before, g._state))
