@@ -84,6 +84,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--bwd-chunk", type=int, default=None, help="particles per flow-backward chunk (tuning)")
     ap.add_argument("--meas-samples", type=int, default=1_000_000, help="ground-truth samples behind the measurements")
+    ap.add_argument("--fused-adamw", action="store_true",
+                    help="torch.optim.AdamW(fused=True): one optimizer kernel instead of ~13 foreach launches (same update)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a hipGraph (mentflow_amd.graph.GraphedTrainStep): the launch-bound small-batch "
                          "regime, e.g. --per-gpu 25000; single GPU only")
@@ -293,7 +295,8 @@ def run_worker(args) -> int:
         per_gpu, global_batch = weak_per_gpu, weak_per_gpu * world
     prob = build_problem(device=device, penalty_parameter=500.0, meas_samples=args.meas_samples, **w)  # same seed: same weights
     model = prob.model
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0, capturable=bool(args.graph))   # experiments/setup.py:166-170
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0, capturable=bool(args.graph),
+                            **({"fused": True} if args.fused_adamw else {}))                             # experiments/setup.py:166-170
     torch.manual_seed(1234 + rank)                                           # every rank draws its own particles
     if args.graph and (world > 1 or emulated):
         raise SystemExit("--graph is a single-GPU mode")

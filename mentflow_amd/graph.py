@@ -57,9 +57,8 @@ class GraphedTrainStep:
         return L.detach(), Hd, Dm, torch.stack([L.detach(), Hd, Dm])
 
     def recapture(self) -> None:
-        for p in self.model.parameters():
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
+        # (gradient tensors are created by the warm-up steps below: the flow generator installs views of ONE flat gradient
+        # buffer, which is what keeps the captured accumulation a single kernel)
         before = self._state_tensors()
         saved = [t.detach().clone() for t in before]
         # warm-up on a side stream (allocator, lazy optimizer state), as torch.cuda.graphs requires

@@ -109,12 +109,16 @@ class FlowSampleFn(torch.autograd.Function):
     Replaces zuko ``NormalizingFlow.rsample_and_log_prob`` as called by
     mentflow/generate/flows/zuko.py:24-26 (base draw z injected) and its autograd backward.
     Saved for backward: the T layer inputs (N x d each) and the packed images; everything else is recomputed.
-    """
+
+    Two ways to receive the parameter gradient: (a) ``flat`` is an autograd tensor (e.g. ``torch.cat`` of the parameters):
+    its gradient is returned to autograd; (b) ``flat`` is a plain buffer, ``trigger`` a leaf that requires grad (so that
+    autograd calls this backward) and ``grad_sink(gflat)`` deposits the gradient (AutoregressiveFlow: one flat copy
+    into the parameters' .grad views instead of one accumulation kernel per parameter)."""
 
     @staticmethod
-    def forward(ctx, z: torch.Tensor, flat: torch.Tensor, spec: FlowSpec, grad_reduce=None):
+    def forward(ctx, z: torch.Tensor, flat: torch.Tensor, spec: FlowSpec, grad_reduce=None, trigger=None, grad_sink=None):
         z = _f32c(z)
-        flat = _f32c(flat)
+        flat = _f32c(flat.detach())
         n = z.shape[0]
         images = pack_images(spec, flat)
         logp = torch.empty(n, dtype=_F32, device=z.device)
@@ -125,6 +129,7 @@ class FlowSampleFn(torch.autograd.Function):
             xs.append(y)
         ctx.spec = spec
         ctx.grad_reduce = grad_reduce
+        ctx.grad_sink = grad_sink
         ctx.save_for_backward(images, *xs[:-1])
         ctx.mark_non_differentiable()
         return xs[-1], logp
@@ -161,7 +166,10 @@ class FlowSampleFn(torch.autograd.Function):
             gflat = part if gflat is None else gflat + part
         if ctx.grad_reduce is not None:
             ctx.grad_reduce(gflat)
-        return None, gflat, None, None
+        if ctx.grad_sink is not None:
+            ctx.grad_sink(gflat)
+            return None, None, None, None, None, None
+        return None, gflat, None, None, None, None
 
 
 def flow_layers_forward(z: torch.Tensor, flat: torch.Tensor, spec: FlowSpec) -> Tuple[List[torch.Tensor], torch.Tensor]:

@@ -274,3 +274,56 @@ def test_inverse_and_log_prob_match_oracle(backend, d, kind, bins, steep):
     lp_err_oracle32 = (of.log_prob(x, s32) - lp64).abs().max()
     lp_tol = 2e-4 if not steep else 10 * float(lp_err_oracle32) + 2e-3
     assert (lp.cpu() - lp64).abs().max() < lp_tol
+
+
+def test_flat_parameter_storage_keeps_autograd_semantics(backend):
+    """The flow's parameters are views of one flat buffer and its backward deposits ONE flat gradient: .grad must still
+    behave as autograd's would — accumulate over backward calls, survive zero_grad in both modes, optimizer steps,
+    load_state_dict, deepcopy and user-installed gradient tensors."""
+    import copy
+    gen = make_generator(backend, 3, transforms=2, bins=8, steep=False)
+    torch.manual_seed(21)
+    z = torch.randn(40, 3).to(backend)
+    w = torch.randn(40, 3).to(backend)
+
+    def backward_once():
+        x, lp = gen.sample_and_log_prob(40, z=z)
+        ((x * w).sum() + lp.sum()).backward()
+        return torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).clone()
+
+    g1 = backward_once()                                            # grads were None -> assigned
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(gen.parameters(), gen._gviews))
+    g2 = backward_once()                                            # accumulates: 2 g
+    torch.testing.assert_close(g2, 2 * g1, rtol=1e-6, atol=0)
+    gen.zero_grad(set_to_none=False)                                # zeros, same tensors
+    assert float(torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).abs().max()) == 0.0
+    assert torch.equal(backward_once(), g1)
+    gen.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in gen.parameters())
+    assert torch.equal(backward_once(), g1)
+    # user-installed gradient tensors: per-parameter accumulation still right
+    for p in gen.parameters():
+        p.grad = torch.ones_like(p)
+    g3 = backward_once()
+    torch.testing.assert_close(g3, g1 + 1.0, rtol=1e-6, atol=1e-6)
+    # parameters are views of flat_parameters(): an optimizer step on them moves the flat buffer the kernels read
+    flat0 = gen.flat_parameters().clone()
+    opt = torch.optim.SGD(gen.parameters(), lr=0.1)
+    gen.zero_grad()
+    g = backward_once()
+    opt.step()
+    torch.testing.assert_close(gen.flat_parameters(), flat0 - 0.1 * g, rtol=1e-6, atol=1e-7)
+    # state_dict round trip + deepcopy independence
+    sd = copy.deepcopy(gen.state_dict())
+    gen2 = copy.deepcopy(gen)
+    with torch.no_grad():
+        for p in gen.parameters():
+            p.add_(1.0)
+    assert not torch.equal(gen.flat_parameters(), gen2.flat_parameters())
+    gen.load_state_dict(sd)
+    assert torch.equal(gen.flat_parameters(), gen2.flat_parameters())
+    with torch.no_grad():
+        xa, _ = gen.sample_and_log_prob(40, z=z)
+        xb, _ = gen2.sample_and_log_prob(40, z=z)
+    assert torch.equal(xa, xb)
+    assert list(gen.state_dict().keys()) == list(gen2.state_dict().keys()) and "_trigger" not in "".join(gen.state_dict().keys())
