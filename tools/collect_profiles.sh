@@ -7,7 +7,7 @@ TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT/stats $OUT/fetch $OUT/write $OUT/sq
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats/bench.json 2> $OUT/stats/err.txt
 echo "stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > /dev/null 2> $OUT/fetch/err.txt
@@ -16,5 +16,16 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $
 echo "write done"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq -- $BENCH > /dev/null 2> $OUT/sq/err.txt
 echo "sq done"
+# C5 (2-D KDE dominant after the flow): kernel stats + SQ counters
+mkdir -p $OUT/c5_stats $OUT/c5_sq
+BENCH5="python3 $GRAFT_REPO_ROOT/bench.py --workload c5 --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_stats -- $BENCH5 > $OUT/c5_stats/bench.json 2> $OUT/c5_stats/err.txt
+echo "c5 stats done"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS --output-format csv -d $OUT/c5_sq -- $BENCH5 > /dev/null 2> $OUT/c5_sq/err.txt
+echo "c5 sq done"
 cd $GRAFT_REPO_ROOT && python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python3 bench.py --scaling strong --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_strong_n1.json 2> $OUT/bench_strong_n1.err
+python3 bench.py --workload c5 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+MENTFLOW_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline > $OUT/bench_2ranks_shared.json 2> $OUT/bench_2ranks_shared.err
+echo "${2:-unknown}" > $OUT/commit.txt
 tail -c 1500 $OUT/bench_default.json

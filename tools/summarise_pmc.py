@@ -38,7 +38,8 @@ def one(pattern):
 stats = one("stats/**/*kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
-for f in ("stats/bench.json", "bench_default.json"):
+for f in ("stats/bench.json", "bench_default.json", "bench_strong_n1.json", "bench_c5.json", "bench_2ranks_shared.json",
+          "c5_stats/bench.json"):
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_" + f.replace("/", "_")))
@@ -70,18 +71,30 @@ if fetch and write:
         fh.write("kernel,launches,FETCH_SIZE_KB_per_launch(raw),WRITE_SIZE_KB_per_launch,HBM_bytes_per_launch(2*fetch+write)\n")
         for r in rows:
             fh.write("%s,%d,%.1f,%.1f,%.0f\n" % r)
+    # provenance: bench.py reports these numbers only for the workload / batch / backward variant that was profiled
+    meta = {"workload": "c4", "per_gpu": 2097152, "fused_bwd": True, "tag": tag,
+            "command": "python3 bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline"}
+    try:
+        meta["commit"] = open(os.path.join(src, "commit.txt")).read().strip()
+    except OSError:
+        pass
+    traffic["_meta"] = meta
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 
-sq = one("sq/**/*counter_collection.csv")
-if sq:
-    agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in csv.DictReader(open(sq)):
-        k = short(r["Kernel_Name"])
-        if k:
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-    names = sorted({n for v in agg.values() for n in v})
-    with open(os.path.join(dst, f"{tag}_sq_counters.csv"), "w") as fh:
-        fh.write("kernel," + ",".join(names) + "\n")
-        for k, v in agg.items():
-            fh.write(k + "," + ",".join("%.4g" % v[n] for n in names) + "\n")
+c5stats = one("c5_stats/**/*kernel_stats.csv")
+if c5stats:
+    shutil.copy(c5stats, os.path.join(dst, f"{tag}_c5_kernel_stats.csv"))
+for sub, name in (("sq", f"{tag}_sq_counters.csv"), ("c5_sq", f"{tag}_c5_sq_counters.csv")):
+  sq = one(sub + "/**/*counter_collection.csv")
+  if sq:
+      agg = collections.defaultdict(lambda: collections.defaultdict(float))
+      for r in csv.DictReader(open(sq)):
+          k = short(r["Kernel_Name"])
+          if k:
+              agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+      names = sorted({n for v in agg.values() for n in v})
+      with open(os.path.join(dst, name), "w") as fh:
+          fh.write("kernel," + ",".join(names) + "\n")
+          for k, v in agg.items():
+              fh.write(k + "," + ",".join("%.4g" % v[n] for n in names) + "\n")
 print("wrote", sorted(os.listdir(dst)))
