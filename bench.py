@@ -224,10 +224,19 @@ def parity_gate(prob, n: int = 36864):
     g = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
     gen.inject_z = saved
     model.zero_grad()
-    Lo, Ho, Do, go = oracle_step(prob, z)
-    res = {"particles": n, "L_abs_err": abs(float(L) - float(Lo)), "H_abs_err": abs(float(H) - float(Ho)),
-           "D_max_abs_err": float((torch.stack(D).detach().cpu() - torch.stack(Do)).abs().max()),
-           "grad_max_err_over_max_grad": float((g - go).abs().max() / go.abs().max()), "L": float(Lo)}
+    # the oracle in fp64 is the reference value; the same oracle in fp32 (what the reference itself would compute on the
+    # CPU) is reported next to it: at this batch size its own rounding noise in the parameter gradients (sums of 36 864
+    # cancelling terms) is of the same order as the kernels'
+    Lo, Ho, Do, go = oracle_step(prob, z, torch.float64)
+    L32, H32, D32, g32 = oracle_step(prob, z, torch.float32)
+    gmax = float(go.abs().max())
+    res = {"particles": n, "reference": "oracle in fp64",
+           "L_abs_err": abs(float(L) - float(Lo)), "H_abs_err": abs(float(H) - float(Ho)),
+           "D_max_abs_err": float((torch.stack(D).detach().cpu().double() - torch.stack(Do)).abs().max()),
+           "grad_max_err_over_max_grad": float((g.double() - go).abs().max() / gmax), "L": float(Lo),
+           "fp32_oracle_vs_fp64": {"L_abs_err": abs(float(L32) - float(Lo)),
+                                   "grad_max_err_over_max_grad": float((g32.double() - go).abs().max() / gmax)},
+           "grad_max_err_vs_fp32_oracle": float((g.double() - g32.double()).abs().max() / gmax)}
     mu = float(model.penalty_parameter)
     res["ok"] = bool(res["L_abs_err"] < 1e-4 + mu * 2e-6 + 2e-5 * abs(float(Lo)) and res["H_abs_err"] < 1e-4
                      and res["grad_max_err_over_max_grad"] < 5e-4)

@@ -251,11 +251,14 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
 
     // soft clip + softmax over this half's K logits.  The clipped logits lie in (-3.46, 3.46), so exp() cannot
     // overflow and the usual max subtraction (a no-op mathematically) is not needed.
-    float p[K];
+    // (the adjoint needs d soft_clip / dv = ia^2 again: keep ia instead of re-evaluating the reciprocal)
+    float p[K], ia2[MODE == 1 ? K : 1];
     float sum = 0.0f;
 #pragma unroll
     for (int m = 0; m < K; ++m) {
-        p[m] = fast_exp(soft_clip(v[m], A2));
+        const float ia = fast_rcp(fmaf(fabsf(v[m]), A2, 1.0f));
+        if (MODE == 1) ia2[m] = ia * ia;
+        p[m] = fast_exp(v[m] * ia);
         sum += p[m];
     }
     const float inv = 1.0f / sum;
@@ -366,11 +369,11 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
         const float gcA = inrange ? 2.0f * RQS_BOUND * (hh ? gy0 : gx0) : 0.0f;
         const float gcB = inrange ? 2.0f * RQS_BOUND * (hh ? gy1 : gx1) : 0.0f;
         const float dot = gcA * ck + gcB * ck1;
+        // d/d(cumulative probability) reaches logit m through every knot >= m + 1: both knots (m < k), the upper one
+        // (m == k) or none; three candidates, two selects per logit
+        const float t_lt = (gcA + gcB) - dot, t_eq = gcB - dot, t_gt = 0.0f - dot;
 #pragma unroll
-        for (int m = 0; m < K; ++m) {
-            const float gp = ((m < k) ? gcA : 0.0f) + ((m <= k) ? gcB : 0.0f);
-            g[m] = p[m] * (gp - dot) * soft_clip_grad(v[m], A2);
-        }
+        for (int m = 0; m < K; ++m) g[m] = p[m] * ((m < k) ? t_lt : ((m == k) ? t_eq : t_gt)) * ia2[m];
         const float gr0 = inrange ? Gd0 * d0 * soft_clip_grad(r0, A1) : 0.0f;
         const float gr1 = inrange ? Gd1 * d1 * soft_clip_grad(r1, A1) : 0.0f;
 #pragma unroll
@@ -664,6 +667,70 @@ __device__ __forceinline__ void chain64(f32x16_t& acc, const float* wl, int g0, 
 #endif
 }
 
+// Two chains over the SAME B operand back to back (the two 32-row tiles of one product): acc0 += A0 * B, acc1 += A1 * B,
+// NG k-step groups each.  The last group of the first chain requests the first fragments of the second (no exposed LDS
+// round trip between them) and only one MFMA -> VALU drain is paid.  NG is a template parameter: the fragment buffers
+// ping-pong by group parity, which must stay a compile-time register choice.
+template <int KS, int NG, class BOp>
+__device__ __forceinline__ void chain64x2(f32x16_t& acc0, f32x16_t& acc1, const float* wl0, const float* wl1, const BOp& b) {
+    static_assert(NG >= 1 && NG <= 8, "1..8 groups");
+#ifdef MF_ASM_CHAIN
+    const unsigned addr0 = lds_addr(wl0), addr1 = lds_addr(wl1);
+    float a0[4], a1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a0[j] = wl0[kcol(j) * KS];
+    // first chain: group G multiplies buffer (G & 1) and fills the other one with group G + 1 of chain 0, or with group 0
+    // of chain 1 when it is the last
+#define MF_A(G, CUR, NXT)                                                                                             \
+    if constexpr (G < NG) {                                                                                          \
+        if constexpr (G + 1 < NG)                                                                                    \
+            mfma4_pf<KS, (4 * G + 4) & 31>(acc0, CUR, NXT, addr0, b.template get<4 * G>(), b.template get<4 * G + 1>(), \
+                                           b.template get<4 * G + 2>(), b.template get<4 * G + 3>());                \
+        else                                                                                                         \
+            mfma4_pf<KS, 0>(acc0, CUR, NXT, addr1, b.template get<4 * G>(), b.template get<4 * G + 1>(),             \
+                            b.template get<4 * G + 2>(), b.template get<4 * G + 3>());                               \
+    }
+    MF_A(0, a0, a1) MF_A(1, a1, a0) MF_A(2, a0, a1) MF_A(3, a1, a0) MF_A(4, a0, a1) MF_A(5, a1, a0) MF_A(6, a0, a1) MF_A(7, a1, a0)
+#undef MF_A
+    // second chain: its group G sits in buffer ((NG + G) & 1)
+#define MF_B(G, CUR, NXT)                                                                                             \
+    if constexpr (G < NG) {                                                                                          \
+        if constexpr (G + 1 < NG)                                                                                    \
+            mfma4_pf<KS, (4 * G + 4) & 31>(acc1, CUR, NXT, addr1, b.template get<4 * G>(), b.template get<4 * G + 1>(), \
+                                           b.template get<4 * G + 2>(), b.template get<4 * G + 3>());                \
+        else                                                                                                         \
+            mfma4_last(acc1, CUR, b.template get<4 * G>(), b.template get<4 * G + 1>(), b.template get<4 * G + 2>(),  \
+                       b.template get<4 * G + 3>());                                                                 \
+    }
+    if constexpr ((NG & 1) == 0) {
+        MF_B(0, a0, a1) MF_B(1, a1, a0) MF_B(2, a0, a1) MF_B(3, a1, a0) MF_B(4, a0, a1) MF_B(5, a1, a0) MF_B(6, a0, a1) MF_B(7, a1, a0)
+    } else {
+        MF_B(0, a1, a0) MF_B(1, a0, a1) MF_B(2, a1, a0) MF_B(3, a0, a1) MF_B(4, a1, a0) MF_B(5, a0, a1) MF_B(6, a1, a0) MF_B(7, a0, a1)
+    }
+#undef MF_B
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));      // MFMA -> VALU read distance, once for both
+#else
+    chain64<KS>(acc0, wl0, 0, NG, b);
+    chain64<KS>(acc1, wl1, 0, NG, b);
+#endif
+}
+// run-time number of groups (wave-uniform): ONE branch into straight-line instances
+template <int KS, class BOp>
+__device__ __forceinline__ void chain64x2_upto(f32x16_t& acc0, f32x16_t& acc1, const float* wl0, const float* wl1, int ng,
+                                               const BOp& b) {
+    switch (ng) {
+        case 0: break;
+        case 1: chain64x2<KS, 1>(acc0, acc1, wl0, wl1, b); break;
+        case 2: chain64x2<KS, 2>(acc0, acc1, wl0, wl1, b); break;
+        case 3: chain64x2<KS, 3>(acc0, acc1, wl0, wl1, b); break;
+        case 4: chain64x2<KS, 4>(acc0, acc1, wl0, wl1, b); break;
+        case 5: chain64x2<KS, 5>(acc0, acc1, wl0, wl1, b); break;
+        case 6: chain64x2<KS, 6>(acc0, acc1, wl0, wl1, b); break;
+        case 7: chain64x2<KS, 7>(acc0, acc1, wl0, wl1, b); break;
+        default: chain64x2<KS, 8>(acc0, acc1, wl0, wl1, b); break;
+    }
+}
+
 // input layer as ONE group of four k-steps (features 2s + hh): columns >= d multiply xb = 0 (the image words read there
 // are other, finite, weights), so no bounds are needed
 __device__ __forceinline__ void input_layer4(const float* W0, const float* b0, int S0, const float (&xb)[4], f32x16_t (&h)[2],
@@ -712,7 +779,7 @@ __device__ __forceinline__ void chain64_upto(f32x16_t& acc, const float* wl, int
 
 // Diagnostic build only (-DMF_WS_DIAG): cycle stamps of pair 0 of every workgroup, read back with mf_debug_ws_read.
 #if defined(MF_WS_DIAG) && !defined(MF_EMU)
-__device__ unsigned long long g_ws_diag[NUM_CU * 16];
+__device__ unsigned long long g_ws_diag[NUM_CU * 4 * 16];      // [workgroup][wave][slot]
 #define WS_T() __builtin_amdgcn_s_memtime()
 #define WS_ACC(var, t0) var += WS_T() - (t0)
 #else
@@ -876,6 +943,27 @@ __device__ __forceinline__ void pair_reduce_bias(float* X, int wid, int lane, fl
     if (!(wid & 1)) bsum += X[(wid >> 1) * 64 + lane];
 }
 
+// timing-ablation switches of the diagnostic build (tools/fb_diag.py, WS_DIAG_FLAGS): results are WRONG with any of them
+#ifdef MF_FB_NO_BARRIER
+#define FB_SYNC() ((void)0)
+#else
+#define FB_SYNC() __syncthreads()
+#endif
+#ifdef MF_FB_NO_DW
+#define FB_DW(...) ((void)0)
+#else
+#define FB_DW(...) dw_accum(__VA_ARGS__)
+#endif
+#ifdef MF_FB_NO_SPLINE
+#define FB_SPLINE(...)                                                                                               \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int m_ = 0; m_ < 32; ++m_) gv[m_] = v[m_] * gyi;                                       \
+        gxd = gl; yi = xi; li = 0.0f;                                                                                \
+    } while (0)
+#else
+#define FB_SPLINE(...) __VA_ARGS__
+#endif
+
 template <int K, int L>
 __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const float* __restrict__ image, int d,
                                                                         const float* __restrict__ x, int64_t n,
@@ -977,19 +1065,17 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
 #pragma unroll
             for (int l = 1; l < L; ++l) {
                 const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    h[l][rt] = bias_tile(W + HID * WS, rt, hh);
-                    // trunk chains run DENSE here: 8 straight-line groups (64 MFMAs) beat the 5 + 8 mask-bounded groups
-                    // (52 MFMAs) whose wave-uniform branches break the ds_read / MFMA pipelining of a lone wave
-                    chain64<1>(h[l][rt], W + (32 * rt + col) * WS + 4 * hh, 0, 8, BTile{l == 1 ? h0 : h[l - 1]});
-                }
+                h[l][0] = bias_tile(W + HID * WS, 0, hh);
+                h[l][1] = bias_tile(W + HID * WS, 1, hh);
+                // trunk chains run DENSE here: 8 straight-line groups (64 MFMAs) beat the 5 + 8 mask-bounded groups
+                // (52 MFMAs) whose wave-uniform branches break the ds_read / MFMA pipelining of a lone wave
+                chain64x2<1, 8>(h[l][0], h[l][1], W + col * WS + 4 * hh, W + (32 + col) * WS + 4 * hh, BTile{l == 1 ? h0 : h[l - 1]});
                 relu2(h[l]);
             }
             if (L == 1) { h[0][0] = h0[0]; h[0][1] = h0[1]; }
         }
         WS_ACC(c_[0], t0_);
-        __syncthreads();                                   // the previous group's last product has read S_A / S_B
+        FB_SYNC();                                   // the previous group's last product has read S_A / S_B
         stage_tile(myB, sl, h[L - 1]);
         // ---- output blocks: spline forward + adjoint, dL/dh_last, last-layer weight gradients
         f32x16_t gh[2];
@@ -1018,11 +1104,10 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             t0_ = WS_T();
             {
                 f32x16_t phi[2];
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    phi[rt] = bias_tile(lds + offB3c + i * HID, rt, hh);
-                    chain64_upto<WS>(phi[rt], W3 + 4 * hh * WS + 32 * rt + col, (kend3_i + 3) >> 2, BTile{h[L - 1]});
-                }
+                phi[0] = bias_tile(lds + offB3c + i * HID, 0, hh);
+                phi[1] = bias_tile(lds + offB3c + i * HID, 1, hh);
+                chain64x2_upto<WS>(phi[0], phi[1], W3 + 4 * hh * WS + col, W3 + 4 * hh * WS + 32 + col, (kend3_i + 3) >> 2,
+                                   BTile{h[L - 1]});
 #pragma unroll
                 for (int m = 0; m < 32; ++m) v[m] = phi[m >> 4][m & 15];
             }
@@ -1035,12 +1120,12 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 gyi = (i == j) ? gyr[j] : gyi;
             }
             float yi, li, gxd;
-            rqs_apply<K, 1>(v, xi, hh, yi, li, gyi, gl, gv, gxd);
+            FB_SPLINE(rqs_apply<K, 1>(v, xi, hh, yi, li, gyi, gl, gv, gxd));
             WS_ACC(c_[2], t0_);
 #pragma unroll
             for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
             t0_ = WS_T();
-            if (i > 0) __syncthreads();                    // product i-1 has read S_A
+            if (i > 0) FB_SYNC();                    // product i-1 has read S_A
             WS_ACC(c_[3], t0_);
             t0_ = WS_T();
             stage_tile(myA, sl, gv);
@@ -1048,16 +1133,18 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             // gh += W3_i^T gphi_i BEFORE the meeting point of the product: the chain gives the four waves ~3 k cycles of
             // slack at barrier B, and gphi (32 registers) is dead by the time the product's fragments are live
             t0_ = WS_T();
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                if (rt ? rt1_i != 0 : kend3_i > 0) {               // hidden tile rt receives something from block i
-                    const int c = 32 * rt + col;
-                    chain64<1>(gh[rt], (c < nc ? W3 + c * WS : zrow) + 4 * hh, 0, 8, BVec{gv});
+            if (kend3_i > 0) {                                     // hidden tile 0 receives something from block i
+                const float* r0 = (col < nc ? W3 + col * WS : zrow) + 4 * hh;
+                if (rt1_i != 0) {                                  // ... and so does hidden tile 1
+                    const float* r1 = (32 + col < nc ? W3 + (32 + col) * WS : zrow) + 4 * hh;
+                    chain64x2<1, 8>(gh[0], gh[1], r0, r1, BVec{gv});
+                } else {
+                    chain64<1>(gh[0], r0, 0, 8, BVec{gv});
                 }
             }
             WS_ACC(c_[8], t0_);
             t0_ = WS_T();
-            __syncthreads();
+            FB_SYNC();
             WS_ACC(c_[5], t0_);
             t0_ = WS_T();
             {
@@ -1065,7 +1152,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 const int ra = full ? fra : hra, rb = full ? frb : 0;
                 const int t0 = full ? 0 : ht0, t1 = full ? 2 : 1;
                 const bool mm = kend3_i > 0;
-                dw_accum(SA, SB, ra, rb, t0, t1, mm, full ? frb : -1, lane, accF, bsF);
+                FB_DW(SA, SB, ra, rb, t0, t1, mm, full ? frb : -1, lane, accF, bsF);
                 WS_ACC(c_[6], t0_);
             }
         };
@@ -1116,13 +1203,13 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 for (int r = 0; r < 16; ++r) gh[rt][r] = (h[l][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
             t1_ = WS_T();
             if (l == 1) input_layer4(lds + g.offW0, lds + g.offB0, g.S0, xb, h[0], col, hh);
-            __syncthreads();                               // the previous product has read S_A / S_B
+            FB_SYNC();                               // the previous product has read S_A / S_B
             stage_tile(myA, sl, gh);
             stage_tile(myB, sl, h[l - 1]);
-            __syncthreads();
+            FB_SYNC();
             WS_ACC(c_[12], t1_);
             t1_ = WS_T();
-            dw_accum(SA, SB, fra, frb, 0, 2, !(fra == 0 && frb == 1 && sp.kend_h[0] <= 16), frb, lane, accT[l], bsT[l]);
+            FB_DW(SA, SB, fra, frb, 0, 2, !(fra == 0 && frb == 1 && sp.kend_h[0] <= 16), frb, lane, accT[l], bsT[l]);
             WS_ACC(c_[13], t1_);
             t1_ = WS_T();
             f32x16_t t[2];
@@ -1133,9 +1220,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             }
             {
                 const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-                    chain64<WS>(t[rt], W + 4 * hh * WS + 32 * rt + col, 0, 8, BTile{gh});
+                chain64x2<WS, 8>(t[0], t[1], W + 4 * hh * WS + col, W + 4 * hh * WS + 32 + col, BTile{gh});
             }
             gh[0] = t[0];
             gh[1] = t[1];
@@ -1146,15 +1231,15 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) gh[rt][r] = (h[0][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
-        __syncthreads();
+        FB_SYNC();
         stage_tile(myA, sl, gh);
         if (hh == 0) {                                     // S_B rows 0..d-1 <- x (rows >= d: stale finite values, never flushed)
 #pragma unroll
             for (int j = 0; j < FB_DMAX; ++j)
                 if (j < d) myB[j * 32 + ((((col >> 2) ^ (j >> 1)) & 7) << 2) + (col & 3)] = xr[j];
         }
-        __syncthreads();
-        dw_accum(SA, SB, hra, 0, ht0, 1, true, -1, lane, accT[0], bsT[0]);
+        FB_SYNC();
+        FB_DW(SA, SB, hra, 0, ht0, 1, true, -1, lane, accT[0], bsT[0]);
         WS_ACC(c_[15], t1_);
         WS_ACC(c_[9], t0_);
         t0_ = WS_T();
@@ -1208,8 +1293,8 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
 #if defined(MF_WS_DIAG) && !defined(MF_EMU)
     __builtin_amdgcn_s_waitcnt(0);
     c_[7] = WS_T() - t0_;                                  // slot 7: the final flush, once per workgroup
-    if (threadIdx.x == 0)
-        for (int q = 0; q < 16; ++q) g_ws_diag[blockIdx.x * 16 + q] = c_[q];
+    if (lane == 0)
+        for (int q = 0; q < 16; ++q) g_ws_diag[(blockIdx.x * 4 + wid) * 16 + q] = c_[q];
 #endif
 }
 
@@ -2151,6 +2236,6 @@ extern "C" int mf_flow_affine_layer_inv(const float* image, int d, int hidden_la
 
 #if defined(MF_WS_DIAG) && !defined(MF_EMU)
 extern "C" int mf_debug_ws_read(unsigned long long* host_out) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mf::g_ws_diag), sizeof(unsigned long long) * NUM_CU * 16) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mf::g_ws_diag), sizeof(unsigned long long) * NUM_CU * 4 * 16) == hipSuccess ? 0 : 1;
 }
 #endif

@@ -25,13 +25,18 @@ for it in range(2):
     x, lp = gen.sample_and_log_prob(n, z=z)
     (x.sum() / n + lp.mean()).backward()
 torch.cuda.synchronize()
-raw = (ctypes.c_ulonglong * (256 * 16))()
+raw = (ctypes.c_ulonglong * (256 * 4 * 16))()
 h = ctypes.CDLL(lib)
 assert h.mf_debug_ws_read(raw) == 0
-a = np.array(raw, dtype=np.float64).reshape(256, 16)
+aw = np.array(raw, dtype=np.float64).reshape(256, 4, 16)      # [workgroup][wave][slot]
+a = aw[:, 0, :]
 groups = (n // 32) / 4 / 256
 names = ["trunk fwd", "phi = W3 h (x d)", "rqs_apply (x d)", "barrier A (x d)", "stage gv (x d)", "barrier B (x d)",
          "dW last layer (x d)", "final flush (x groups!)", "gh += W3^T gv (x d)", "trunk bwd + dW", "gx", "TOTAL", " trunk: stage+barriers", " trunk: dW (x2)", " trunk: W^T chains (x2)", " level 0: stage + dW"]
 print("groups per workgroup:", groups, " (ticks of s_memtime, 100 MHz: x21 for 2.1 GHz cycles)")
 for q, nm in enumerate(names):
     print(f"  {nm:24s} {a[:, q].mean() / groups:9.1f} ticks per group   {100 * a[:, q].mean() / a[:, 11].mean():5.1f} %")
+
+print("per-wave view (mean over workgroups, ticks per group):")
+for q in (0, 1, 2, 3, 5, 6, 8, 9, 11):
+    print(f"  {names[q]:24s} " + "  ".join(f"w{w}: {aw[:, w, q].mean() / groups:9.1f}" for w in range(4)))
