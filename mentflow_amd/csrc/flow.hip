@@ -667,52 +667,56 @@ __device__ __forceinline__ void chain64(f32x16_t& acc, const float* wl, int g0, 
 #endif
 }
 
-// Two chains over the SAME B operand back to back (the two 32-row tiles of one product): acc0 += A0 * B, acc1 += A1 * B,
-// NG k-step groups each.  The last group of the first chain requests the first fragments of the second (no exposed LDS
-// round trip between them) and only one MFMA -> VALU drain is paid.  NG is a template parameter: the fragment buffers
-// ping-pong by group parity, which must stay a compile-time register choice.
-template <int KS, int NG, class BOp>
-__device__ __forceinline__ void chain64x2(f32x16_t& acc0, f32x16_t& acc1, const float* wl0, const float* wl1, const BOp& b) {
-    static_assert(NG >= 1 && NG <= 8, "1..8 groups");
+// Two chains over the SAME B operand back to back (the two 32-row tiles of one product): acc0 += A0 * B over the k-step
+// groups [S0, E0), acc1 += A1 * B over [S1, E1) (mask-bounded ranges: the skipped groups only multiply zeros).  The last
+// group of the first chain requests the first fragments of the second (no exposed LDS round trip between them) and only
+// one MFMA -> VALU drain is paid.  The ranges are template parameters: the fragment buffers ping-pong by position in the
+// sequence, which must stay a compile-time register choice.
+#ifdef MF_ASM_CHAIN
+template <int KS, int G, int NEXT_S, class BOp>     // NEXT_S: first k-step of the group to prefetch, -1: none
+__device__ __forceinline__ void chain_grp(f32x16_t& acc, const float (&cur)[4], float (&nxt)[4], unsigned addr_next, const BOp& b) {
+    if constexpr (NEXT_S >= 0)
+        mfma4_pf<KS, NEXT_S>(acc, cur, nxt, addr_next, b.template get<4 * G>(), b.template get<4 * G + 1>(),
+                             b.template get<4 * G + 2>(), b.template get<4 * G + 3>());
+    else
+        mfma4_last(acc, cur, b.template get<4 * G>(), b.template get<4 * G + 1>(), b.template get<4 * G + 2>(),
+                   b.template get<4 * G + 3>());
+}
+#endif
+template <int KS, int S0, int E0, int S1, int E1, class BOp>
+__device__ __forceinline__ void chain64x2r(f32x16_t& acc0, f32x16_t& acc1, const float* wl0, const float* wl1, const BOp& b) {
+    static_assert(0 <= S0 && S0 < E0 && E0 <= 8 && 0 <= S1 && S1 < E1 && E1 <= 8, "non-empty group ranges within 0..8");
 #ifdef MF_ASM_CHAIN
     const unsigned addr0 = lds_addr(wl0), addr1 = lds_addr(wl1);
     float a0[4], a1[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a0[j] = wl0[kcol(j) * KS];
-    // first chain: group G multiplies buffer (G & 1) and fills the other one with group G + 1 of chain 0, or with group 0
-    // of chain 1 when it is the last
-#define MF_A(G, CUR, NXT)                                                                                             \
-    if constexpr (G < NG) {                                                                                          \
-        if constexpr (G + 1 < NG)                                                                                    \
-            mfma4_pf<KS, (4 * G + 4) & 31>(acc0, CUR, NXT, addr0, b.template get<4 * G>(), b.template get<4 * G + 1>(), \
-                                           b.template get<4 * G + 2>(), b.template get<4 * G + 3>());                \
-        else                                                                                                         \
-            mfma4_pf<KS, 0>(acc0, CUR, NXT, addr1, b.template get<4 * G>(), b.template get<4 * G + 1>(),             \
-                            b.template get<4 * G + 2>(), b.template get<4 * G + 3>());                               \
+    for (int j = 0; j < 4; ++j) a0[j] = wl0[kcol(4 * S0 + j) * KS];
+#define MF_A(G)                                                                                                       \
+    if constexpr (G >= S0 && G < E0) {                                                                               \
+        constexpr bool last_ = (G + 1 == E0);                                                                        \
+        constexpr int nxt_ = last_ ? 4 * S1 : 4 * G + 4;                                                             \
+        if constexpr (((G - S0) & 1) == 0) chain_grp<KS, G, nxt_>(acc0, a0, a1, last_ ? addr1 : addr0, b);           \
+        else chain_grp<KS, G, nxt_>(acc0, a1, a0, last_ ? addr1 : addr0, b);                                         \
     }
-    MF_A(0, a0, a1) MF_A(1, a1, a0) MF_A(2, a0, a1) MF_A(3, a1, a0) MF_A(4, a0, a1) MF_A(5, a1, a0) MF_A(6, a0, a1) MF_A(7, a1, a0)
+    MF_A(0) MF_A(1) MF_A(2) MF_A(3) MF_A(4) MF_A(5) MF_A(6) MF_A(7)
 #undef MF_A
-    // second chain: its group G sits in buffer ((NG + G) & 1)
-#define MF_B(G, CUR, NXT)                                                                                             \
-    if constexpr (G < NG) {                                                                                          \
-        if constexpr (G + 1 < NG)                                                                                    \
-            mfma4_pf<KS, (4 * G + 4) & 31>(acc1, CUR, NXT, addr1, b.template get<4 * G>(), b.template get<4 * G + 1>(), \
-                                           b.template get<4 * G + 2>(), b.template get<4 * G + 3>());                \
-        else                                                                                                         \
-            mfma4_last(acc1, CUR, b.template get<4 * G>(), b.template get<4 * G + 1>(), b.template get<4 * G + 2>(),  \
-                       b.template get<4 * G + 3>());                                                                 \
+#define MF_B(G)                                                                                                       \
+    if constexpr (G >= S1 && G < E1) {                                                                               \
+        constexpr int nxt_ = (G + 1 == E1) ? -1 : 4 * G + 4;                                                         \
+        if constexpr ((((E0 - S0) + (G - S1)) & 1) == 0) chain_grp<KS, G, nxt_>(acc1, a0, a1, addr1, b);             \
+        else chain_grp<KS, G, nxt_>(acc1, a1, a0, addr1, b);                                                         \
     }
-    if constexpr ((NG & 1) == 0) {
-        MF_B(0, a0, a1) MF_B(1, a1, a0) MF_B(2, a0, a1) MF_B(3, a1, a0) MF_B(4, a0, a1) MF_B(5, a1, a0) MF_B(6, a0, a1) MF_B(7, a1, a0)
-    } else {
-        MF_B(0, a1, a0) MF_B(1, a0, a1) MF_B(2, a1, a0) MF_B(3, a0, a1) MF_B(4, a1, a0) MF_B(5, a0, a1) MF_B(6, a1, a0) MF_B(7, a0, a1)
-    }
+    MF_B(0) MF_B(1) MF_B(2) MF_B(3) MF_B(4) MF_B(5) MF_B(6) MF_B(7)
 #undef MF_B
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));      // MFMA -> VALU read distance, once for both
 #else
-    chain64<KS>(acc0, wl0, 0, NG, b);
-    chain64<KS>(acc1, wl1, 0, NG, b);
+    chain64<KS>(acc0, wl0, S0, E0, b);
+    chain64<KS>(acc1, wl1, S1, E1, b);
 #endif
+}
+template <int KS, int NG, class BOp>
+__device__ __forceinline__ void chain64x2(f32x16_t& acc0, f32x16_t& acc1, const float* wl0, const float* wl1, const BOp& b) {
+    chain64x2r<KS, 0, NG, 0, NG>(acc0, acc1, wl0, wl1, b);
 }
 // run-time number of groups (wave-uniform): ONE branch into straight-line instances
 template <int KS, class BOp>
@@ -1069,7 +1073,19 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 h[l][1] = bias_tile(W + HID * WS, 1, hh);
                 // trunk chains run DENSE here: 8 straight-line groups (64 MFMAs) beat the 5 + 8 mask-bounded groups
                 // (52 MFMAs) whose wave-uniform branches break the ds_read / MFMA pipelining of a lone wave
-                chain64x2<1, 8>(h[l][0], h[l][1], W + col * WS + 4 * hh, W + (32 + col) * WS + 4 * hh, BTile{l == 1 ? h0 : h[l - 1]});
+                {
+                    // mask-bounded: output tile 0 only sees the k-steps [0, kend_h[0]) (4, 5, 6 or 8 groups of four for
+                    // d = 3/5, 6, 4, 2); tile 1 sees all of them.  One switch into straight-line pairs.
+                    const float* w0 = W + col * WS + 4 * hh;
+                    const float* w1 = W + (32 + col) * WS + 4 * hh;
+                    const BTile bt{l == 1 ? h0 : h[l - 1]};
+                    switch ((sp.kend_h[0] + 3) >> 2) {
+                        case 4: chain64x2r<1, 0, 4, 0, 8>(h[l][0], h[l][1], w0, w1, bt); break;
+                        case 5: chain64x2r<1, 0, 5, 0, 8>(h[l][0], h[l][1], w0, w1, bt); break;
+                        case 6: chain64x2r<1, 0, 6, 0, 8>(h[l][0], h[l][1], w0, w1, bt); break;
+                        default: chain64x2r<1, 0, 8, 0, 8>(h[l][0], h[l][1], w0, w1, bt); break;
+                    }
+                }
                 relu2(h[l]);
             }
             if (L == 1) { h[0][0] = h0[0]; h[0][1] = h0[1]; }
@@ -1220,7 +1236,15 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             }
             {
                 const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
-                chain64x2<WS, 8>(t[0], t[1], W + 4 * hh * WS + col, W + 4 * hh * WS + 32 + col, BTile{gh});
+                // transposed: input-unit tile 1 only receives from the k-steps [kbeg_ht[1], 32)
+                const float* w0 = W + 4 * hh * WS + col;
+                const float* w1 = w0 + 32;
+                switch (sp.kbeg_ht[1] >> 2) {
+                    case 2: chain64x2r<WS, 0, 8, 2, 8>(t[0], t[1], w0, w1, BTile{gh}); break;
+                    case 3: chain64x2r<WS, 0, 8, 3, 8>(t[0], t[1], w0, w1, BTile{gh}); break;
+                    case 4: chain64x2r<WS, 0, 8, 4, 8>(t[0], t[1], w0, w1, BTile{gh}); break;
+                    default: chain64x2r<WS, 0, 8, 0, 8>(t[0], t[1], w0, w1, BTile{gh}); break;
+                }
             }
             gh[0] = t[0];
             gh[1] = t[1];
