@@ -21,6 +21,7 @@ extern "C" {
 #endif
 
 #define MF_ABI_VERSION 2
+#define MF_ENTROPY_SCRATCH_DOUBLES 2048
 
 int mf_abi_version(void);
 const char* mf_last_error(void);
@@ -112,9 +113,10 @@ int mf_flow_affine_layer_inv(const float* image, int d, int hidden_layers, const
  * Only the 2*radius+1 bins around each projected particle are visited (dropped kernel values are below
  * exp(-(radius+1/2)^2 delta^2 / (2 sigma^2)), 3e-18 for the reference's sigma = delta/2 and radius 4); pass
  * radius >= B for the dense sum.                                                                              */
-/* ws: mf_proj_kde_ws_bytes(P, bins) bytes of scratch: one [lo | hi] pair of 64-bit INTEGER accumulators per bin.
- * Weights are summed as 2^-50 fixed-point integers at every level (64-bit LDS atomics inside a workgroup, 64-bit
- * integer global atomics of the low / high halves across workgroups): exact, order independent, bitwise reproducible. */
+/* ws: mf_proj_kde_ws_bytes(P, bins) bytes of scratch: one 64-bit INTEGER accumulator per bin.
+ * Weights are summed as fixed-point integers at every level (2^-50 units with 64-bit LDS atomics inside a workgroup,
+ * one 64-bit integer global atomic per bin and workgroup in 2^(s-50) units, s = max(0, ceil(log2 n) - 13): exact up to
+ * 8192 particles per call): order independent, bitwise reproducible.                                            */
 int64_t mf_proj_kde_ws_bytes(int P, int bins);
 int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* V, int P, const float* coords, int B,
                       float sigma, int radius, float* S, void* ws, void* stream);
@@ -169,7 +171,8 @@ int mf_hist_norm_discrepancy_bwd(const float* S, int P, int bins, int normalize,
 /* ------------------------------------------------------------------------------------------------------------
  * Monte-Carlo entropy sums  (mentflow/entropy.py:58-62 + mentflow/prior.py:25-26):
  *   out[0] = sum_n logp[n],  out[1] = sum_n |x_n|^2      (means / prior constants applied by the caller after
- *   any cross-GPU sum; scratch2 = two doubles of device scratch).
+ *   any cross-GPU sum; scratch2 = MF_ENTROPY_SCRATCH_DOUBLES doubles of device scratch: per-workgroup fp64 partials,
+ *   summed in a fixed order — no atomics, bitwise reproducible).
  *   mf_scale_rows: gx[n,:] (+)= coef[0] * cscale * x[n,:]  — the adjoint of the |x|^2 term; coef is a DEVICE
  *   scalar (the upstream gradient) so that no host synchronisation is needed.                                 */
 int mf_mc_entropy_sums(const float* x, const float* logp, int64_t n, int d, float* out2, double* scratch2,

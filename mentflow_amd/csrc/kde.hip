@@ -16,8 +16,8 @@
 // Accumulation is FIXED POINT and therefore exact and order independent at every level: each weight (<= 1) is
 // converted to a 2^-50 integer and added with 64-bit integer LDS atomics (8.9e-16 quantum: far-tail bins, whose log
 // enters the KL discrepancy, keep their relative accuracy); a workgroup (<= 8192 particles: 2^13 * 2^50 < 2^64) flushes
-// the low and the high 32 bits of every non-zero bin with two 64-bit INTEGER global atomics, and a finishing kernel
-// rebuilds hi * 2^32 + lo, scales by 2^-50 and rounds to fp32 once.  The histograms are bitwise reproducible.
+// every non-zero bin with ONE 64-bit INTEGER global atomic (2^(shift-50) units, exact up to 8192 particles per call,
+// see fix_flush), and a finishing kernel scales and rounds to fp32 once.  Integer sums do not depend on their order: the histograms are bitwise reproducible.
 // Measured on MI355X (tools/ubench_lds_atomics*.hip): ds_add_f32 sustains 0.33 lane-ops/clk/CU, ds_add_u64 2.7 with
 // random addresses (bank conflicts between the 16 lanes of a group) — the float LDS atomic is 8x slower.  The image can
 // be REPLICATED (COPIES = 1, 2, 4, 8, 16): copy c = lane & (COPIES - 1) of entry e lives at e * COPIES + c, so the lanes
@@ -69,13 +69,20 @@ __device__ __forceinline__ u64 to_fix(float w) {
     return ((u64)hi << 32) | (u64)lo;
 }
 
-// exact flush of one workgroup's bin total v (< 2^64) into the global accumulator pair [lo | hi] of the bin
-__device__ __forceinline__ void fix_flush(u64* __restrict__ acc2, u64 v) {
-    if (v != 0) {
-        atomicAdd(&acc2[0], v & 0xffffffffull);
-        const u64 hi = v >> 32;
-        if (hi != 0) atomicAdd(&acc2[1], hi);
-    }
+// flush of one workgroup's bin total v (2^-50 units, < 2^64) into the bin's 64-bit global accumulator: ONE integer atomic
+// per non-zero bin and workgroup.  The global sum of n particles needs log2(n) more bits than a weight, so the
+// accumulator is kept in 2^(shift-50) units with shift = max(0, ceil(log2 n) - 13): EXACT (shift 0) up to 8192 particles
+// per call, 2^-43 units at 2 M, 2^-40 at 16 M.  The dropped bits cost at most one unit per flush: relative to a bin
+// total that is n * 2^-76 / (density * bin width), 2e-6 of a 1e-10 density at 2 M particles — far below the reference's
+// own 1e-12 padding — and integer addition keeps the result independent of the order of the workgroups.
+__device__ __forceinline__ void fix_flush(u64* __restrict__ acc, u64 v, int shift) {
+    v >>= shift;
+    if (v != 0) atomicAdd(acc, v);
+}
+static int kde_global_shift(int64_t n) {
+    int k = 0;
+    while (((int64_t)1 << k) < n) ++k;
+    return k > 13 ? k - 13 : 0;
 }
 
 // Gaussian window on a UNIFORM grid, factorised: with kc the centre bin of u, r0 = (u - c_kc) / sigma and
@@ -145,7 +152,7 @@ __device__ __forceinline__ void stage_vrows(float* Vl, const float* __restrict__
 template <int RT, int BLOCK>   // RT > 0: compile-time window radius (factorised weights);  RT == 0: runtime radius
 __global__ __launch_bounds__(BLOCK) void proj_kde1d_fwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V, int P, int Pg,
-    const float* __restrict__ coords, int B, float inv_sigma, int Rrt, u64* __restrict__ Sacc, int per_wg) {
+    const float* __restrict__ coords, int B, float inv_sigma, int Rrt, u64* __restrict__ Sacc, int per_wg, int gshift) {
     MF_DYN_SMEM(u64, lds);
     u64* img = lds;
     float* Vl = reinterpret_cast<float*>(img + (size_t)Pg * B);
@@ -196,14 +203,14 @@ __global__ __launch_bounds__(BLOCK) void proj_kde1d_fwd_kernel(
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < np * B; i += BLOCK) fix_flush(Sacc + 2 * ((int64_t)p_begin * B + i), img[i]);
+    for (int i = threadIdx.x; i < np * B; i += BLOCK) fix_flush(Sacc + (int64_t)p_begin * B + i, img[i], gshift);
 }
 
-// S[i] = fp32( (hi * 2^32 + lo) * 2^-50 )
+// S[i] = fp32(acc[i] * 2^(shift-50))
 __global__ __launch_bounds__(KDE_BLOCK) void acc_to_float_kernel(const u64* __restrict__ Sacc, float* __restrict__ S,
-                                                                  int64_t total) {
+                                                                  int64_t total, double unit) {
     for (int64_t i = (int64_t)blockIdx.x * KDE_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * KDE_BLOCK)
-        S[i] = (float)(((double)Sacc[2 * i + 1] * 4294967296.0 + (double)Sacc[2 * i]) * KDE_FIX_INV);
+        S[i] = (float)((double)Sacc[i] * unit);
 }
 
 // ------------------------------------------------------------------------------------------------ 1-D backward
@@ -298,7 +305,7 @@ template <int RT, int BLOCK>   // RT == 4: both radii are 4 (factorised weights,
 __global__ __launch_bounds__(BLOCK) void proj_kde2d_fwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V0, const float* __restrict__ V1, int P,
     int Pg, const float* __restrict__ coords_x, int Bx, float inv_sx, int Rx, const float* __restrict__ coords_y,
-    int By, float inv_sy, int Ry, u64* __restrict__ Sacc, int per_wg) {
+    int By, float inv_sy, int Ry, u64* __restrict__ Sacc, int per_wg, int gshift) {
     MF_DYN_SMEM(u64, lds);
     const int BB = Bx * By;
     u64* img = lds;
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(BLOCK) void proj_kde2d_fwd_kernel(
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < np * BB; i += BLOCK) fix_flush(Sacc + 2 * ((int64_t)p_begin * BB + i), img[i]);
+    for (int i = threadIdx.x; i < np * BB; i += BLOCK) fix_flush(Sacc + (int64_t)p_begin * BB + i, img[i], gshift);
 }
 
 // ------------------------------------------------------------------------------------------------ 2-D backward
@@ -697,14 +704,18 @@ __global__ __launch_bounds__(KDE_BLOCK) void mc_entropy_sums_kernel(const float*
     }
     const double tl = block_sum(sl, red);
     const double tq = block_sum(sq, red);
-    if (threadIdx.x == 0) {
-        atomicAdd(&acc2[0], tl);
-        atomicAdd(&acc2[1], tq);
+    if (threadIdx.x == 0) {                       // per-workgroup partials, summed in a fixed order by the finish kernel
+        acc2[2 * blockIdx.x] = tl;
+        acc2[2 * blockIdx.x + 1] = tq;
     }
 }
 
-__global__ void entropy_finish_kernel(const double* __restrict__ acc2, float* __restrict__ out2) {
-    if (threadIdx.x < 2) out2[threadIdx.x] = (float)acc2[threadIdx.x];
+__global__ void entropy_finish_kernel(const double* __restrict__ acc2, int nparts, float* __restrict__ out2) {
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int i = 0; i < nparts; ++i) t += acc2[2 * i + threadIdx.x];
+        out2[threadIdx.x] = (float)t;
+    }
 }
 
 __global__ __launch_bounds__(KDE_BLOCK) void scale_rows_kernel(const float* __restrict__ x, int64_t total,
@@ -809,11 +820,12 @@ static int kde_check(int64_t n, int d, int P, int B) {
     return 0;
 }
 
-// workspace of the forward kernels: one [lo | hi] pair of 64-bit integer accumulators per bin
-extern "C" int64_t mf_proj_kde_ws_bytes(int P, int bins) { return 2 * (int64_t)P * bins * (int64_t)sizeof(u64); }
+// workspace of the forward kernels: one 64-bit integer accumulator per bin
+extern "C" int64_t mf_proj_kde_ws_bytes(int P, int bins) { return (int64_t)P * bins * (int64_t)sizeof(u64); }
 
-static int fix_finish(const u64* Sacc, float* S, int64_t total, void* stream) {
-    MF_LAUNCH(acc_to_float_kernel, grid_for(total, KDE_BLOCK, 1024), KDE_BLOCK, 0, stream, Sacc, S, total);
+static int fix_finish(const u64* Sacc, float* S, int64_t total, int shift, void* stream) {
+    MF_LAUNCH(acc_to_float_kernel, grid_for(total, KDE_BLOCK, 1024), KDE_BLOCK, 0, stream, Sacc, S, total,
+              KDE_FIX_INV * (double)((u64)1 << shift));
     return check_launch("acc_to_float");
 }
 
@@ -838,7 +850,7 @@ extern "C" int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* 
                                   float sigma, int radius, float* S, void* ws, void* stream) {
     if (kde_check(n, d, P, B)) return 1;
     u64* Sfix = reinterpret_cast<u64*>(ws);
-    if (hipMemsetAsync(Sfix, 0, 2 * sizeof(u64) * (size_t)P * B, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
+    if (hipMemsetAsync(Sfix, 0, sizeof(u64) * (size_t)P * B, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
     if (n > 0) {
         const int R = radius < 0 ? 0 : (radius > B ? B : radius);
         const size_t per_proj = sizeof(u64) * (size_t)B + sizeof(float) * KDE_VS;
@@ -847,9 +859,10 @@ extern "C" int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* 
         // (the reference's 25 000 particles): 256 threads and many small projection groups so that ~4 * NUM_CU
         // workgroups exist.
         const bool small = n <= 65536;
-        // tuned on MI355X at C4 (tools/kde_sweep.py, profiles/r02_kde_sweep.txt): 1024 threads, ~52 KiB images (two
-        // workgroups = 32 waves per CU), 8 workgroup waves over the chip: 1.11 ms against 1.19-1.51 ms for 256 threads
-        static const int block_env = env_int("MENTFLOW_KDE1D_BLOCK", 0), waves_env = env_int("MENTFLOW_KDE1D_WAVES", 8);
+        // tuned on MI355X at C4 (tools/kde_sweep.py, profiles/r02_kde_sweep_1d.txt): 1024 threads, ~52 KiB images (two
+        // workgroups = 32 waves per CU): 1.11-1.13 ms against 1.19-1.51 ms for 256 threads; 4 workgroup waves over the
+        // chip (4096 particles per workgroup at C4) rather than 8: 2 % slower, half the flush atomics
+        static const int block_env = env_int("MENTFLOW_KDE1D_BLOCK", 0), waves_env = env_int("MENTFLOW_KDE1D_WAVES", 4);
         static const int lds_env = env_int("MENTFLOW_KDE1D_LDS", 0);
         const int block = block_env ? block_env : (small ? 256 : 1024);
         size_t budget = lds_env ? (size_t)lds_env : (size_t)52 * 1024;
@@ -879,7 +892,7 @@ extern "C" int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* 
     if (!launched && (R == 4) == (RTV == 4) && block == BL) {                                                         \
         MF_ALLOW_DYN_SMEM((proj_kde1d_fwd_kernel<RTV, BL>), smem);                                                    \
         MF_LAUNCH((proj_kde1d_fwd_kernel<RTV, BL>), dim3((unsigned)G, ngroups), BL, smem, stream, x, n, d, V, P, Pg,   \
-                  coords, B, 1.0f / sigma, R, Sfix, per_wg);                                                          \
+                  coords, B, 1.0f / sigma, R, Sfix, per_wg, kde_global_shift(n));                                                          \
         launched = true;                                                                                              \
     }
         KDE1D_CASE(4, 256) KDE1D_CASE(0, 256) KDE1D_CASE(4, 512) KDE1D_CASE(0, 512) KDE1D_CASE(4, 1024) KDE1D_CASE(0, 1024)
@@ -887,7 +900,7 @@ extern "C" int mf_proj_kde1d_fwd(const float* x, int64_t n, int d, const float* 
         if (!launched) return fail("no 1-D KDE forward instance for block=%d (256, 512, 1024)", block);
         if (check_launch("mf_proj_kde1d_fwd")) return 1;
     }
-    return fix_finish(Sfix, S, (int64_t)P * B, stream);
+    return fix_finish(Sfix, S, (int64_t)P * B, kde_global_shift(n), stream);
 }
 
 extern "C" int mf_proj_kde1d_bwd(const float* x, int64_t n, int d, const float* V, int P, const float* coords, int B,
@@ -939,7 +952,7 @@ extern "C" int mf_proj_kde2d_fwd(const float* x, int64_t n, int d, const float* 
     if (kde2d_check(d, P, Bx, By, radius_x, radius_y, sizeof(u64))) return 1;
     const int BB = Bx * By;
     u64* Sfix = reinterpret_cast<u64*>(ws);
-    if (hipMemsetAsync(Sfix, 0, 2 * sizeof(u64) * (size_t)P * BB, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
+    if (hipMemsetAsync(Sfix, 0, sizeof(u64) * (size_t)P * BB, (hipStream_t)stream) != hipSuccess) return fail("memset ws");
     if (n > 0) {
         // tuned on MI355X at C5 (tools/kde_sweep.py): one 85 x 85 image (58 KiB) per 1024-thread workgroup, two
         // workgroups per CU: 6.0 ms against 6.7 (512 threads) / 9-16 ms (256 threads, the r01 shape)
@@ -964,7 +977,8 @@ extern "C" int mf_proj_kde2d_fwd(const float* x, int64_t n, int d, const float* 
     if (!launched && RT == RTV && block == BL) {                                                                      \
         MF_ALLOW_DYN_SMEM((proj_kde2d_fwd_kernel<RTV, BL>), smem);                                                    \
         MF_LAUNCH((proj_kde2d_fwd_kernel<RTV, BL>), dim3((unsigned)G, ngroups), BL, smem, stream, x, n, d, V0, V1, P,  \
-                  Pg, coords_x, Bx, 1.0f / sigma_x, radius_x, coords_y, By, 1.0f / sigma_y, radius_y, Sfix, per_wg);   \
+                  Pg, coords_x, Bx, 1.0f / sigma_x, radius_x, coords_y, By, 1.0f / sigma_y, radius_y, Sfix, per_wg,        \
+                  kde_global_shift(n));   \
         launched = true;                                                                                              \
     }
         KDE2D_CASE(4, 256) KDE2D_CASE(0, 256) KDE2D_CASE(4, 512) KDE2D_CASE(0, 512) KDE2D_CASE(4, 1024) KDE2D_CASE(0, 1024)
@@ -972,7 +986,7 @@ extern "C" int mf_proj_kde2d_fwd(const float* x, int64_t n, int d, const float* 
         if (!launched) return fail("no 2-D KDE forward instance for block=%d (256, 512, 1024)", block);
         if (check_launch("mf_proj_kde2d_fwd")) return 1;
     }
-    return fix_finish(Sfix, S, (int64_t)P * BB, stream);
+    return fix_finish(Sfix, S, (int64_t)P * BB, kde_global_shift(n), stream);
 }
 
 extern "C" int mf_proj_kde2d_bwd(const float* x, int64_t n, int d, const float* V0, const float* V1, int P,
@@ -1096,12 +1110,14 @@ extern "C" int mf_hist_norm_discrepancy_bwd(const float* S, int P, int bins, int
 extern "C" int mf_mc_entropy_sums(const float* x, const float* logp, int64_t n, int d, float* out2, double* acc2,
                                    void* stream) {
     if (d < 1) return fail("d must be >= 1");
-    if (hipMemsetAsync(acc2, 0, 2 * sizeof(double), (hipStream_t)stream) != hipSuccess) return fail("memset");
+    static_assert(2 * NUM_CU * 4 <= MF_ENTROPY_SCRATCH_DOUBLES, "scratch of mf_mc_entropy_sums");
+    int parts = 0;
     if (n > 0) {
-        MF_LAUNCH(mc_entropy_sums_kernel, grid_for(n, KDE_BLOCK * 4, NUM_CU * 4), KDE_BLOCK, 0, stream, x, logp, n, d, acc2);
+        parts = grid_for(n, KDE_BLOCK * 4, NUM_CU * 4);
+        MF_LAUNCH(mc_entropy_sums_kernel, parts, KDE_BLOCK, 0, stream, x, logp, n, d, acc2);
         if (check_launch("mf_mc_entropy_sums")) return 1;
     }
-    MF_LAUNCH(entropy_finish_kernel, 1, 64, 0, stream, (const double*)acc2, out2);
+    MF_LAUNCH(entropy_finish_kernel, 1, 64, 0, stream, (const double*)acc2, parts, out2);
     return check_launch("mf_mc_entropy_sums(finish)");
 }
 

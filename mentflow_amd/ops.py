@@ -328,7 +328,7 @@ class EntropySumsFn(torch.autograd.Function):
     def forward(ctx, x, logp):
         x, logp = _f32c(x), _f32c(logp)
         out = torch.empty(2, dtype=_F32, device=x.device)
-        scratch = torch.empty(2, dtype=torch.float64, device=x.device)
+        scratch = torch.empty(2048, dtype=torch.float64, device=x.device)      # MF_ENTROPY_SCRATCH_DOUBLES
         call("mf_mc_entropy_sums", ptr(x), ptr(logp), x.shape[0], x.shape[1], ptr(out), ptr(scratch), stream_ptr(x))
         ctx.save_for_backward(x)
         return out

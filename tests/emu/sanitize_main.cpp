@@ -139,7 +139,7 @@ static void kde2d(int64_t n, int d, int P, int Bx, int By, float bwx, float bwy,
 
 static void tail(int64_t n, int d) {
     std::vector<float> x = rnd(n * d, 1.0f), logp = rnd(n, 1.0f), out(2), gx(n * d), coef(1, 0.5f), u(n * d);
-    std::vector<double> acc(2);
+    std::vector<double> acc(MF_ENTROPY_SCRATCH_DOUBLES);
     CK(mf_mc_entropy_sums(x.data(), logp.data(), n, d, out.data(), acc.data(), nullptr));
     CK(mf_scale_rows(x.data(), n, d, coef.data(), 2.0f, gx.data(), 0, nullptr));
     std::vector<int32_t> idx(n);
