@@ -53,7 +53,11 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
     bs.body = std::move(body);
     bs.fibers.resize(nthreads);
     bs.waves.resize((nthreads + WAVE - 1) / WAVE);
-    for (auto& f : bs.fibers) f.stack = (char*)malloc(STACK);
+    // fiber stacks come from a pool that lives as long as the process: a launch of 1024 threads would otherwise map and
+    // unmap 512 MiB every time (minutes of kernel time over a test run, more under ASan)
+    static std::vector<char*> stack_pool;
+    while ((int)stack_pool.size() < nthreads) stack_pool.push_back((char*)malloc(STACK));
+    for (int i = 0; i < nthreads; ++i) bs.fibers[i].stack = stack_pool[i];
     GuardedLds dyn(smem);
     bs.dyn_smem = dyn.block;
     BlockState* prev = g_block;
@@ -96,7 +100,6 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
                     if (++spins > 200000000L) { fprintf(stderr, "emu: deadlock (divergent collective?)\n"); abort(); }
                 }
             }
-    for (auto& f : bs.fibers) free(f.stack);
     g_block = prev;
 }
 
