@@ -4,6 +4,33 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#ifdef MF_EMU_FAST_SWITCH
+// void mf_emu_ctx_switch(Ctx* from, Ctx* to): push the callee-saved registers, park the stack pointer in *from, adopt
+// *to's, pop its callee-saved registers and return into it.
+asm(R"(
+    .text
+    .globl mf_emu_ctx_switch
+    .type mf_emu_ctx_switch, @function
+mf_emu_ctx_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size mf_emu_ctx_switch, .-mf_emu_ctx_switch
+)");
+#endif
+
 namespace emu {
 
 BlockState* g_block = nullptr;
@@ -15,7 +42,12 @@ static void fiber_entry() {
     b->body();
     b->fibers[b->cur].done = true;
     MF_FIBER_START(nullptr, b->sched_bottom, b->sched_size);         // this fiber never runs again
+#ifdef MF_EMU_FAST_SWITCH
+    mf_emu_ctx_switch(&b->fibers[b->cur].ctx, &b->sched);
+#else
     swapcontext(&b->fibers[b->cur].ctx, &b->sched);
+#endif
+    abort();                                                         // not reached
 }
 
 // Guard-paged dynamic LDS: [ PROT_NONE page | slack ... block (size bytes, 64-byte aligned start) | PROT_NONE page ]
@@ -77,11 +109,24 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
                             Fiber& f = bs.fibers[t];
                             f.done = false;
                             f.tid = dim3(tx, ty, tz);
+#ifdef MF_EMU_FAST_SWITCH
+                            {   // initial frame: six zeroed callee-saved registers, then fiber_entry as the return address,
+                                // then a null return address for fiber_entry itself (it never returns); the stack pointer
+                                // is congruent to 8 mod 16 when fiber_entry starts, as after a call
+                                uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+                                void** sp = (void**)top;
+                                *--sp = nullptr;
+                                *--sp = (void*)fiber_entry;
+                                for (int r = 0; r < 6; ++r) *--sp = nullptr;
+                                f.ctx.sp = sp;
+                            }
+#else
                             getcontext(&f.ctx);
                             f.ctx.uc_stack.ss_sp = f.stack;
                             f.ctx.uc_stack.ss_size = STACK;
                             f.ctx.uc_link = nullptr;
                             makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+#endif
                         }
                 int remaining = nthreads;
                 long spins = 0;
@@ -93,7 +138,11 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
                         bs.cur = i;
                         g_threadIdx = f.tid;
                         MF_FIBER_START(&bs.sched_fake_stack, f.stack, STACK);
+#ifdef MF_EMU_FAST_SWITCH
+                        mf_emu_ctx_switch(&bs.sched, &f.ctx);
+#else
                         swapcontext(&bs.sched, &f.ctx);
+#endif
                         MF_FIBER_FINISH(bs.sched_fake_stack, nullptr, nullptr);
                         if (f.done) { --remaining; ++progressed; }
                     }

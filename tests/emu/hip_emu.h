@@ -80,8 +80,21 @@ extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t 
 #define MF_FIBER_FINISH(save, bottom_old, size_old) ((void)0)
 #endif
 
+// Context switch between the scheduler and the fibers.  glibc's swapcontext saves and restores the signal mask with a
+// system call on EVERY switch (tens of millions per test run: most of the emulator's wall time was kernel time), so
+// on x86-64 a six-register hand-written switch is used instead; other hosts keep ucontext.
+#if defined(__x86_64__)
+#define MF_EMU_FAST_SWITCH 1
+struct Ctx {
+    void* sp = nullptr;
+};
+extern "C" void mf_emu_ctx_switch(Ctx* from, Ctx* to);
+#else
+typedef ucontext_t Ctx;
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Ctx ctx;
     char* stack = nullptr;
     bool done = false;
     dim3 tid;
@@ -101,7 +114,7 @@ struct BlockState {
     int cur = 0;
     int barrier_arrived = 0;
     unsigned barrier_gen = 0;
-    ucontext_t sched;
+    Ctx sched;
     std::function<void()> body;
     // dynamic LDS of the workgroup: EXACTLY the requested size, its end on a PROT_NONE guard page (and, under ASan,
     // the alignment slack in front of it poisoned): an out-of-range LDS index in a kernel faults on the CPU
@@ -118,7 +131,11 @@ inline void yield() {
     BlockState* b = g_block;
     Fiber& f = b->fibers[b->cur];
     MF_FIBER_START(&f.fake_stack, b->sched_bottom, b->sched_size);
+#ifdef MF_EMU_FAST_SWITCH
+    mf_emu_ctx_switch(&f.ctx, &b->sched);
+#else
     swapcontext(&f.ctx, &b->sched);
+#endif
     MF_FIBER_FINISH(f.fake_stack, nullptr, nullptr);
 }
 
