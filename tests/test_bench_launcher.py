@@ -73,3 +73,14 @@ def test_bench_two_ranks_share_gpu():
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2
     assert j["backend"] == ("nccl" if two else "gloo")
     assert j["roofline"]["kernel"].startswith("flow_layer")
+
+
+@pytest.mark.gpu
+def test_bench_graph_mode_small_batch():
+    """`--graph --fused-adamw`: the hipGraph-replayed step at the reference's 25 000-particle batch prints a valid line."""
+    r = _run(["--workload", "c3", "--per-gpu", "25000", "--steps", "20", "--warmup", "3", "--repeats", "2", "--no-cpu-baseline",
+              "--meas-samples", "50000", "--graph", "--fused-adamw"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and "hipGraph" in j["config"]["step"] and j["config"]["global_batch"] == 25000
+    assert 0.1 < j["ms_per_step"] < 5.0
