@@ -1177,21 +1177,6 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         // (register moves; FB_DMAX / 2 iterations bring every block back to its place).  A switch on i made the
         // register allocator copy all six blocks at every merge; rotating after every feature cost twice the moves.
         static_assert(FB_DMAX % 2 == 0, "two features per iteration");
-#ifdef MF_FB_SINGLE_FEATURE      // experiment: one inlined copy of the feature body (smaller code), rotate by one
-#pragma unroll 1
-        for (int i = 0; i < FB_DMAX; ++i) {
-            if (i < d) feature(i, accO[0], bsO[0]);
-            const f32x16_t ta0 = accO[0];
-            const float tb0 = bsO[0];
-#pragma unroll
-            for (int k = 0; k + 1 < FB_DMAX; ++k) {
-                accO[k] = accO[k + 1];
-                bsO[k] = bsO[k + 1];
-            }
-            accO[FB_DMAX - 1] = ta0;
-            bsO[FB_DMAX - 1] = tb0;
-        }
-#else
 #pragma unroll 1
         for (int i = 0; i < FB_DMAX; i += 2) {
             if (i < d) feature(i, accO[0], bsO[0]);
@@ -1208,7 +1193,6 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             bsO[FB_DMAX - 2] = tb0;
             bsO[FB_DMAX - 1] = tb1;
         }
-#endif
         t0_ = WS_T();
         // ---- trunk backward
 #pragma unroll
