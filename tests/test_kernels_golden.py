@@ -240,3 +240,41 @@ def test_kde1d_backward_nonfinite_rows_same_in_both_window_variants(backend):
     good = [i for i in range(n) if i not in bad]
     # both variants agree on the ordinary rows (bandwidths differ by 0.2 %: loose tolerance, the point is no NaN leak)
     torch.testing.assert_close(outs[0][1][good], outs[1][1][good], rtol=0.05, atol=0.05 * float(outs[0][1].abs().max()))
+
+
+@pytest.mark.parametrize("bw", [0.3, 0.45, 0.6, 1.0])
+def test_kde_other_bandwidths_vs_oracle(backend, bw):
+    """Bandwidths other than the reference default 0.5 bin widths: 0.45 still takes the radius-4 window (exact central
+    bins + factorised tail, s = 2.22), 0.3 / 0.6 / 1.0 the run-time-radius loops (radius 3, 5, 9; 2-D: radius <= 5 only).
+    Values and gradients against the pinned dense oracle (oracle/kde.py, fp64)."""
+    from oracle import kde as okde
+    torch.manual_seed(17)
+    n, B = 700, 40
+    u = torch.randn(n, 2) * 1.3
+    u[0, 0], u[1, 1], u[2, 0] = 3.9, -4.4, 7.0                    # near / beyond the histogram range
+    edges = torch.linspace(-4.0, 4.0, B + 1)
+    w1 = torch.randn(B)
+    # 1-D
+    x = u[:, :1].clone().to(backend).requires_grad_(True)
+    diag = mf.diagnostics.Histogram1D(edges=edges, bandwidth=bw, axis=0).to(backend)
+    hist = diag(x)
+    (hist * w1.to(backend)).sum().backward()
+    xo = u[:, 0].double().clone().requires_grad_(True)
+    ho = okde.kde_histogram_1d(xo, edges.double(), bandwidth=bw * float(edges[1] - edges[0]))
+    (ho * w1.double()).sum().backward()
+    close(hist, ho.float(), 2e-5, 1e-6)
+    close(x.grad[:, 0], xo.grad.float(), 1e-3, 2e-6)
+    if bw > 0.6:
+        return                                                     # the 2-D kernels support radii up to 5 bins
+    # 2-D
+    w2 = torch.randn(B, B)
+    x2 = u.clone().to(backend).requires_grad_(True)
+    d2 = mf.diagnostics.Histogram2D(axis=(0, 1), edges=(edges, edges), bandwidth=(bw, 0.5)).to(backend)
+    h2 = d2(x2)
+    (h2 * w2.to(backend)).sum().backward()
+    uo = u.double().clone().requires_grad_(True)
+    delta = float(edges[1] - edges[0])
+    h2o = okde.kde_histogram_2d(uo[:, 0], uo[:, 1], (edges.double(), edges.double()), bandwidth=(bw * delta, 0.5 * delta))
+    (h2o * w2.double()).sum().backward()
+    close(h2, h2o.float(), 2e-5, 1e-7)
+    close(x2.grad, uo.grad.float(), 1e-3, 2e-6)
