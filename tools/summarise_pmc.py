@@ -31,8 +31,9 @@ def short(name):
 
 
 def one(pattern):
-    files = glob.glob(os.path.join(src, pattern), recursive=True)
-    return files[0] if files else None
+    # gpurun merges every run's output into the same scratch tree: take the NEWEST match, not the first
+    files = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
+    return files[-1] if files else None
 
 
 stats = one("stats/**/*kernel_stats.csv")
