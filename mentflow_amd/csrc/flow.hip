@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                         case 4: chain64x2r<1, 0, 4, 0, 8>(h[l][0], h[l][1], w0, w1, bt); break;
                         case 5: chain64x2r<1, 0, 5, 0, 8>(h[l][0], h[l][1], w0, w1, bt); break;
                         case 6: chain64x2r<1, 0, 6, 0, 8>(h[l][0], h[l][1], w0, w1, bt); break;
-                        default: chain64x2r<1, 0, 8, 0, 8>(h[l][0], h[l][1], w0, w1, bt); break;
+                        default: chain64x2i<1, 8>(h[l][0], h[l][1], w0, w1, bt); break;       // equal ranges: interleaved
                     }
                 }
                 relu2(h[l]);
@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                     case 2: chain64x2r<WS, 0, 8, 2, 8>(t[0], t[1], w0, w1, BTile{gh}); break;
                     case 3: chain64x2r<WS, 0, 8, 3, 8>(t[0], t[1], w0, w1, BTile{gh}); break;
                     case 4: chain64x2r<WS, 0, 8, 4, 8>(t[0], t[1], w0, w1, BTile{gh}); break;
-                    default: chain64x2r<WS, 0, 8, 0, 8>(t[0], t[1], w0, w1, BTile{gh}); break;
+                    default: chain64x2i<WS, 8>(t[0], t[1], w0, w1, BTile{gh}); break;      // equal ranges: interleaved
                 }
             }
             gh[0] = t[0];
@@ -1850,11 +1850,10 @@ __global__ __launch_bounds__(FB_BLOCK) void affine_layer_bwd_fused_kernel(const 
 #pragma unroll
             for (int l = 1; l < L; ++l) {
                 const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    h[l][rt] = bias_tile(W + HID * WS, rt, hh);
-                    chain64<1>(h[l][rt], W + (32 * rt + col) * WS + 4 * hh, 0, 8, BTile{l == 1 ? h0 : h[l - 1]});
-                }
+                h[l][0] = bias_tile(W + HID * WS, 0, hh);
+                h[l][1] = bias_tile(W + HID * WS, 1, hh);
+                // dense image (the affine kernel takes no mask structure): both row tiles over all 8 groups, interleaved
+                chain64x2i<1, 8>(h[l][0], h[l][1], W + col * WS + 4 * hh, W + (32 + col) * WS + 4 * hh, BTile{l == 1 ? h0 : h[l - 1]});
                 relu2(h[l]);
             }
             if (L == 1) { h[0][0] = h0[0]; h[0][1] = h0[1]; }
@@ -1893,11 +1892,10 @@ __global__ __launch_bounds__(FB_BLOCK) void affine_layer_bwd_fused_kernel(const 
         // gh = W3^T gphi: only the 16 slots of row tile 0 are populated (k-step groups 0..3)
         f32x16_t gh[2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) gh[rt][r] = 0.0f;
-            chain64<WS>(gh[rt], W3 + 4 * hh * WS + 32 * rt + col, 0, 4, BVec{gv});
-        }
+        chain64x2i<WS, 4>(gh[0], gh[1], W3 + 4 * hh * WS + col, W3 + 4 * hh * WS + 32 + col, BVec{gv});
         // ---- trunk backward
 #pragma unroll
         for (int l = L - 1; l >= 1; --l) {
@@ -1914,11 +1912,10 @@ __global__ __launch_bounds__(FB_BLOCK) void affine_layer_bwd_fused_kernel(const 
             f32x16_t t[2];
             const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t[rt][r] = 0.0f;
-                chain64<WS>(t[rt], W + 4 * hh * WS + 32 * rt + col, 0, 8, BTile{gh});
-            }
+            chain64x2i<WS, 8>(t[0], t[1], W + 4 * hh * WS + col, W + 4 * hh * WS + 32 + col, BTile{gh});
             gh[0] = t[0];
             gh[1] = t[1];
         }
