@@ -15,6 +15,16 @@ from typing import List, Optional, Tuple
 import torch
 
 
+def _copy_all(dst: List[torch.Tensor], src: List[torch.Tensor]) -> None:
+    """dst[i] <- src[i]: one multi-tensor kernel where torch has it, a loop otherwise."""
+    foreach = getattr(torch, "_foreach_copy_", None)
+    if foreach is not None:
+        foreach(dst, src)
+    else:
+        for d, s in zip(dst, src):
+            d.copy_(s)
+
+
 class GraphedTrainStep:
     """step() -> (L, H, mean D) as device tensors (static buffers, overwritten by the next replay).
 
@@ -83,7 +93,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             if self.guard:
-                torch._foreach_copy_(self._backup, state)
+                _copy_all(self._backup, state)
             self.out = self._eager()
         self._state = state
 
@@ -99,4 +109,4 @@ class GraphedTrainStep:
         if not self.guard:
             raise RuntimeError("GraphedTrainStep(guard=True) is needed to undo a step")
         with torch.no_grad():
-            torch._foreach_copy_(self._state, self._backup)
+            _copy_all(self._state, self._backup)
