@@ -84,3 +84,24 @@ def test_bench_graph_mode_small_batch():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 1 and "hipGraph" in j["config"]["step"] and j["config"]["global_batch"] == 25000
     assert 0.1 < j["ms_per_step"] < 5.0
+
+
+def test_torchrun_launched_ranks_on_the_emulator(emu_library):
+    """The driver's own N > 1 form: `python -m torch.distributed.run ... bench.py --gpus N` (WORLD_SIZE set by the launcher:
+    bench.py must run as a worker, not start ranks of its own)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--per-gpu", "128", "--steps", "1",
+                        "--warmup", "0", "--repeats", "1", "--no-cpu-baseline", "--meas-samples", "2000", "--scaling", "weak",
+                        "--test-emulator-lib", emu_library], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["backend"] == "gloo" and j["config"]["global_batch"] == 256
