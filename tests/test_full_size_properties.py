@@ -200,3 +200,41 @@ def test_16m_particles_indexing_smoke(dev):
     torch.testing.assert_close(g, g_sum, rtol=1e-4, atol=1e-5 * float(g.abs().max()))
     # the tail end of the batch really was processed (last particle's row is not an uninitialised buffer)
     assert float(gx[-1].abs().sum()) > 0 and float(x[-1].abs().sum()) > 0
+
+
+def test_c5_full_size_step_is_reproducible_and_variant_independent(dev, monkeypatch):
+    """C5 at its full per-GPU size: 100 two-dimensional projections x 85 x 85 bins, 2 097 152 particles, the whole
+    MENTFlow.loss() + backward: bitwise reproducible, histograms additive over a split of the batch, and parameter
+    gradients independent of the flow-backward variant."""
+    prob = build_problem(ndim=6, num=100, bins=85, xmax=3.5, seed=0, transforms=5, prior_scale=3.0, device=dev,
+                         dist_name="gaussian_mixture", optics="nd_2d_random", meas_samples=200_000, penalty_parameter=500.0)
+    gen = prob.model.generator
+    n = 2_097_152
+    torch.manual_seed(3)
+    z = torch.randn(n, 6, device=dev)
+    runs = []
+    for fused in ("1", "1", "0"):
+        monkeypatch.setenv("MENTFLOW_BWD_FUSED", fused)
+        gen.inject_z = z
+        prob.model.zero_grad()
+        L, H, D = prob.model.loss(n)
+        L.backward()
+        runs.append((L.detach().clone(), H.detach().clone(), torch.stack(D).detach().clone(),
+                     torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).clone()))
+    monkeypatch.delenv("MENTFLOW_BWD_FUSED")
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b), "C5 step is not bitwise reproducible"
+    assert torch.equal(runs[0][0], runs[2][0]) and torch.equal(runs[0][2], runs[2][2])      # forward is the same code
+    torch.testing.assert_close(runs[0][3], runs[2][3], rtol=2e-4, atol=2e-5 * float(runs[0][3].abs().max()))
+    assert torch.isfinite(runs[0][3]).all() and float(runs[0][3].abs().max()) > 0
+    # 2-D histograms of the full batch = sum over two shards
+    with torch.no_grad():
+        x, _ = gen.sample_and_log_prob(n, z=z)
+    diag = prob.diagnostics[0][0]
+    V0 = torch.stack([t.matrix[0] for t in prob.transforms]).contiguous()
+    V1 = torch.stack([t.matrix[2] for t in prob.transforms]).contiguous()
+    args = (diag.coords_x, diag.coords_y, float(diag.bandwidth_x), float(diag.bandwidth_y), 4, 4)
+    S = ops.ProjKde2dFn.apply(x, V0, V1, *args)
+    Sa = ops.ProjKde2dFn.apply(x[:700_001].contiguous(), V0, V1, *args)
+    Sb = ops.ProjKde2dFn.apply(x[700_001:].contiguous(), V0, V1, *args)
+    torch.testing.assert_close(S, Sa + Sb, rtol=3e-7, atol=1e-6)
