@@ -238,3 +238,31 @@ def test_c5_full_size_step_is_reproducible_and_variant_independent(dev, monkeypa
     Sa = ops.ProjKde2dFn.apply(x[:700_001].contiguous(), V0, V1, *args)
     Sb = ops.ProjKde2dFn.apply(x[700_001:].contiguous(), V0, V1, *args)
     torch.testing.assert_close(S, Sa + Sb, rtol=3e-7, atol=1e-6)
+
+
+def test_kde_results_do_not_depend_on_launch_shape():
+    """The tuning knobs (block size, LDS budget, particles per workgroup; read once per process) must not change a single
+    bit of the histograms (integer accumulation).  The backward sums a particle's projections in registers: its result may
+    only move by fp32 reassociation when the number of lanes sharing a particle changes with the block size."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "kde_sweep.py")
+    outs = {}
+    for kind, cfgs in (("1d", [{}, {"MENTFLOW_KDE1D_BLOCK": "256", "MENTFLOW_KDE1D_WAVES": "8", "MENTFLOW_KDE1D_BWD_BLOCK": "1024"},
+                               {"MENTFLOW_KDE1D_BLOCK": "512", "MENTFLOW_KDE1D_LDS": "159000", "MENTFLOW_KDE1D_WAVES": "2"}]),
+                       ("2d", [{}, {"MENTFLOW_KDE2D_BLOCK": "256", "MENTFLOW_KDE2D_FWD_LDS": "118000", "MENTFLOW_KDE2D_BWD_BLOCK": "256",
+                                    "MENTFLOW_KDE2D_BWD_NPT": "2"}])):
+        for cfg in cfgs:
+            env = dict(os.environ, **cfg)
+            r = subprocess.run([sys.executable, tool, "--kind", kind, "--n", "300000"], env=env, capture_output=True, text=True,
+                               timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            outs.setdefault(kind, []).append((j["sumS"], j["sum|gx|"]))
+    for kind, vals in outs.items():
+        assert len({v[0] for v in vals}) == 1, (kind, vals)
+        for v in vals[1:]:
+            assert abs(v[1] - vals[0][1]) <= 1e-6 * abs(vals[0][1]), (kind, vals)
