@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 

@@ -1,15 +1,12 @@
 """Edge shapes on the kernels (emulated in the CPU suite, the real library with -m gpu): ragged and tiny batches around
 the 32-particle tile and the 4-tile workgroup group of the fused backward, every supported d / bins / hidden_layers
 combination, odd projection / bin counts and d = 1..8 for the projection kernels — against the oracle."""
-import itertools
-
 import pytest
 import torch
 
 import mentflow_amd as mf
 from mentflow_amd import ops
 from oracle import flow as of
-from oracle import kde as okde
 from oracle.harness import flow_spec_from_generator
 
 

@@ -1,7 +1,7 @@
 """Development tool (runs on the GPU box): times the projection + KDE kernels at the C4 / C5 shapes for one setting of
 the MENTFLOW_KDE* tuning variables (read once per process), or — with --sweep — spawns itself over a grid of settings.
     python tools/kde_sweep.py --sweep 1d|2d  > gpurun_out/kde_sweep.txt"""
-import argparse, itertools, json, os, subprocess, sys, time
+import argparse, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
