@@ -74,9 +74,9 @@ def log(msg: str) -> None:
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--per-gpu", type=int, default=None, help="particles per GPU (overrides the scaling mode's batch)")
