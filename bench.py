@@ -238,8 +238,12 @@ def parity_gate(prob, n: int = 36864):
                                    "grad_max_err_over_max_grad": float((g32.double() - go).abs().max() / gmax)},
            "grad_max_err_vs_fp32_oracle": float((g.double() - g32.double()).abs().max() / gmax)}
     mu = float(model.penalty_parameter)
+    # gradients: 5e-4 of the largest entry, or twice the fp32 oracle's own distance to the fp64 one where that is larger
+    # (the sums cancel more and more as the fit converges: after 200 steps both sit near 4e-4)
+    gtol = max(5e-4, 2.0 * res["fp32_oracle_vs_fp64"]["grad_max_err_over_max_grad"])
+    res["grad_gate"] = gtol
     res["ok"] = bool(res["L_abs_err"] < 1e-4 + mu * 2e-6 + 2e-5 * abs(float(Lo)) and res["H_abs_err"] < 1e-4
-                     and res["grad_max_err_over_max_grad"] < 5e-4)
+                     and res["grad_max_err_over_max_grad"] < gtol)
     log("parity gate: " + json.dumps(res))
     return res
 
