@@ -225,12 +225,86 @@ __device__ __forceinline__ void input_layer(const float* W0, const float* b0, in
 // exp(x) as one v_exp_f32: exp2(x * log2(e)).  Only used on soft-clipped arguments (|x| < 6.91), where the rounding of
 // the product costs at most |x| * 1.44 * 2^-24 < 6e-7 relative — the same order as the fp32 rounding of everything
 // downstream; a compensated argument (hi + lo split) was measured to cost ~5 % of the forward kernel.
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
 
 __device__ __forceinline__ float soft_clip(float v, float a) { return v * fast_rcp(fmaf(fabsf(v), a, 1.0f)); }
 __device__ __forceinline__ float soft_clip_grad(float v, float a) {
     const float ia = fast_rcp(fmaf(fabsf(v), a, 1.0f));
     return ia * ia;
+}
+
+// The two lanes (col, col + 32) of a particle exchange a value: lo = the value held by lane col, hi = the one held by
+// lane col + 32, both results in both lanes.  gfx950: ONE v_permlane32_swap_b32 (a VALU instruction; the generic
+// __shfl_xor(v, 32) is a ds_bpermute_b32, i.e. an LDS round trip that a lone wave per SIMD sits through, five times per
+// spline).  v_permlane32_swap vdst, vsrc swaps lanes 32..63 of vdst with lanes 0..31 of vsrc; with the same value in
+// both operands vdst becomes {lo, lo} and vsrc {hi, hi}.
+__device__ __forceinline__ void half_pair(float v, int hh, float& lo, float& hi) {
+#if defined(MF_EMU) || defined(MF_NO_PERMLANE)
+    const float o = __shfl_xor(v, 32);
+    lo = hh ? o : v;
+    hi = hh ? v : o;
+#else
+    (void)hh;
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    lo = __builtin_bit_cast(float, (unsigned)r[0]);
+    hi = __builtin_bit_cast(float, (unsigned)r[1]);
+#endif
+}
+__device__ __forceinline__ void half_pair(int v, int hh, int& lo, int& hi) {
+#if defined(MF_EMU) || defined(MF_NO_PERMLANE)
+    const int o = __shfl_xor(v, 32);
+    lo = hh ? o : v;
+    hi = hh ? v : o;
+#else
+    (void)hh;
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    lo = (int)r[0];
+    hi = (int)r[1];
+#endif
+}
+
+// float -> unsigned with saturation: v_cvt_u32_f32 (negative / NaN -> 0, >= 2^32 -> 0xffffffff).  Written as the
+// instruction itself: a C++ cast leaves out-of-range conversions undefined, and x is unbounded.
+__device__ __forceinline__ unsigned cvt_u32_sat(float f) {
+#ifdef MF_EMU
+    return !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xffffffffu : (unsigned)f);
+#else
+    unsigned r;
+    asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+#endif
+}
+
+// (t[idx], t[idx + 1]) of a table of N + 1 registers for a per-lane index idx in [0, N - 1], as a binary tree of selects on
+// the BITS of idx: the bit masks are formed once (log2 N compares), every select then reads a mask that was written long
+// before.  The linear form "for j: if (idx == j) ..." costs a compare per entry, and on gfx950 a VALU instruction that
+// reads a mask needs two wait states after the VALU compare that wrote it — the compiler pads each compare / select pair
+// with s_nop (80 issue slots for the 21 spline knots; this tree: 29 selects + 9 for the masks).
+// The tree runs over the triples (t[2j], t[2j+1], t[2j+2]); bit 0 of idx picks the pair out of the surviving triple.
+template <int N, typename T>
+__device__ __forceinline__ void select_pair(const T (&t)[N + 1], int idx, T& lo, T& hi) {
+    constexpr int M = (N + 1) / 2;
+    T a[M][3];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        a[j][0] = t[2 * j];
+        a[j][1] = t[2 * j + 1 <= N ? 2 * j + 1 : N];
+        a[j][2] = t[2 * j + 2 <= N ? 2 * j + 2 : N];
+    }
+    const int j2 = idx >> 1;
+#pragma unroll
+    for (int b = 0; (1 << b) < M; ++b) {
+        const bool bit = ((j2 >> b) & 1) != 0;
+#pragma unroll
+        for (int j = 0; j + (1 << b) < M; j += 2 << b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[j][c] = bit ? a[j + (1 << b)][c] : a[j][c];
+    }
+    const bool odd = (idx & 1) != 0;
+    lo = odd ? a[0][1] : a[0][0];
+    hi = odd ? a[0][2] : a[0][1];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -240,6 +314,14 @@ __device__ __forceinline__ float soft_clip_grad(float v, float a) {
 // MODE 0: forward (y, ladj).  MODE 1: forward + adjoint: also returns g[32] = dL/dv (same slot layout) and
 // gx = dL/dx (direct path) for upstream gy = dL/dy, gl = dL/dladj.  MODE 2: inverse — `x` is the transformed value,
 // the bin search runs on the heights (half 1) and y_out returns the pre-image (zuko MonotonicRQSTransform._inverse).
+//
+// Cumulative bin probabilities.  torch.cumsum on the CPU accumulates float32 in double and rounds every prefix to
+// float32 (the reference path).  Here the normalised probabilities are quantised to 2^-31 (round to nearest) and summed as
+// 32-bit integers: the prefix sums are EXACT sums of the quantised terms (|error| <= 20 * 2^-32 = 5e-9, an order of
+// magnitude under the float32 rounding of the prefix itself), converted to float32 once — the same "exact sum, one
+// rounding" the double accumulator gives, for 5 full-rate instructions per bin (fma, cvt, add, compare, add-carry) instead
+// of the 44 cycles of cvt_f64 / add_f64 / cvt_f32.  The bin search compares the integer prefixes with the (exactly
+// converted) query, so it is a total order consistent with the knots that are then used.
 template <int K, int MODE>
 __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh, float& y_out, float& ladj_out,
                                           float gy, float gl, float (&g)[32], float& gx_out) {
@@ -247,67 +329,72 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
     constexpr int KD1 = K - 1 - KD0;      // derivatives owned by half 1
     constexpr float A2 = 2.0f * LOG_SLOPE_INV;
     constexpr float A1 = LOG_SLOPE_INV;
+    constexpr float FIX = 2147483648.0f;  // 2^31: prefix sums <= 1 + 20 * 2^-32 fit 32 bits with headroom
     static_assert(K + KD0 <= 32, "spline does not fit the 32 slots of a lane half");
 
     // soft clip + softmax over this half's K logits.  The clipped logits lie in (-3.46, 3.46), so exp() cannot
-    // overflow and the usual max subtraction (a no-op mathematically) is not needed.
-    // (the adjoint needs d soft_clip / dv = ia^2 again: keep ia instead of re-evaluating the reciprocal)
-    float p[K], ia2[MODE == 1 ? K : 1];
+    // overflow and the usual max subtraction (a no-op mathematically) is not needed.  log2(e) is folded into the
+    // reciprocal: ia = log2(e) / (1 + |v| A2), p = exp2(v * ia).  The adjoint needs d soft_clip / dv = (ia / log2 e)^2:
+    // pq = p * ia^2 is formed here, the constant joins the three per-feature factors below.
+    float p[K], pq[MODE == 1 ? K : 1];
     float sum = 0.0f;
 #pragma unroll
     for (int m = 0; m < K; ++m) {
-        const float ia = fast_rcp(fmaf(fabsf(v[m]), A2, 1.0f));
-        if (MODE == 1) ia2[m] = ia * ia;
-        p[m] = fast_exp(v[m] * ia);
+        const float ia = fast_rcp(fmaf(fabsf(v[m]), A2 / LOG2E, 1.0f / LOG2E));
+        p[m] = __builtin_amdgcn_exp2f(v[m] * ia);
+        if (MODE == 1) pq[m] = p[m] * (ia * ia);
         sum += p[m];
     }
-    const float inv = 1.0f / sum;
-    // cumulative probabilities (torch.cumsum on CPU accumulates in double) and the bin search on the widths, done on
-    // the cumulative probabilities: knot_j < x  <=>  c_j < (x / bound + 1) / 2
-    float cj[K + 1];
-    cj[0] = 0.0f;
-    double c = 0.0;
+    const float inv = fast_rcp(sum);
+    // bin search on the cumulative probabilities:  knot_j < x  <=>  c_j < (x / bound + 1) / 2
+    unsigned cj[K + 1];
+    cj[0] = 0u;
     const float xc = fmaf(x, 0.5f / RQS_BOUND, 0.5f);
+    const unsigned xq = cvt_u32_sat(xc * FIX);          // exact for 0 <= xc < 2 (a power-of-two scaling), saturating outside
+    const float fscale = inv * FIX;
+    unsigned c = 0u;
     int cnt = (-RQS_BOUND < x) ? 1 : 0;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        p[j] *= inv;
-        c += (double)p[j];
-        cj[j + 1] = (float)c;
-        cnt += (cj[j + 1] < xc) ? 1 : 0;
+        c += cvt_u32_sat(fmaf(p[j], fscale, 0.5f));
+        cj[j + 1] = c;
+        cnt += (c < xq) ? 1 : 0;
     }
     {   // both lanes use the count of the half that owns the searched knots: widths (half 0), heights for the inverse
-        const int other = __shfl_xor(cnt, 32);
-        const bool mine = (MODE == 2) ? (hh == 1) : (hh == 0);
-        cnt = mine ? cnt : other;
+        int lo, hi;
+        half_pair(cnt, hh, lo, hi);
+        cnt = (MODE == 2) ? hi : lo;
     }
     const int k = cnt - 1;
     const bool inrange = (cnt >= 1) && (cnt <= K);
-    float ck = 0.0f, ck1 = 1.0f;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const bool sel = (k == j);
-        ck = sel ? cj[j] : ck;
-        ck1 = sel ? cj[j + 1] : ck1;
-    }
+    unsigned qk, qk1;                     // knots k and k + 1 (out of range: the first / last bin, never used)
+    select_pair<K>(cj, min(max(k, 0), K - 1), qk, qk1);
+    const float ck = (float)qk * (1.0f / FIX), ck1 = (float)qk1 * (1.0f / FIX);
     const float kn0 = RQS_BOUND * (2.0f * ck - 1.0f);
     const float kn1 = RQS_BOUND * (2.0f * ck1 - 1.0f);
-    const float on0 = __shfl_xor(kn0, 32);
-    const float on1 = __shfl_xor(kn1, 32);
-    const float x0 = hh ? on0 : kn0, x1 = hh ? on1 : kn1;
-    const float y0 = hh ? kn0 : on0, y1 = hh ? kn1 : on1;
+    float x0, x1, y0, y1;                 // widths live in half 0, heights in half 1
+    half_pair(kn0, hh, x0, y0);
+    half_pair(kn1, hh, x1, y1);
     // raw derivative logits at knots k and k+1 (0 at the boundary knots: exp(0) = 1)
     const int base = hh ? KD0 : 0;
     const int nown = hh ? KD1 : KD0;
-    float r0 = 0.0f, r1 = 0.0f;
+    // table of this half's logits by knot: G[e] = logit of interior knot (base + e - 1), zero for knots the half does
+    // not own (and for the boundary knots); knots k and k + 1 are the adjacent pair at e = k - base + 1
+    float r0, r1;
+    {
+        float G[KD0 + 4];
+        G[0] = G[1] = G[KD0 + 2] = G[KD0 + 3] = 0.0f;
 #pragma unroll
-    for (int j = 0; j < KD0; ++j) {
-        const bool own = j < nown;
-        r0 = (own && (k - 1 == base + j)) ? v[K + j] : r0;
-        r1 = (own && (k == base + j)) ? v[K + j] : r1;
+        for (int j = 0; j < KD0; ++j) G[2 + j] = (j < KD1 || j < nown) ? v[K + j] : 0.0f;
+        select_pair<KD0 + 3>(G, min(max(k - base + 1, 0), KD0 + 2), r0, r1);
     }
-    r0 += __shfl_xor(r0, 32);
-    r1 += __shfl_xor(r1, 32);
+    {
+        float a, b;
+        half_pair(r0, hh, a, b);
+        r0 = a + b;
+        half_pair(r1, hh, a, b);
+        r1 = a + b;
+    }
     const float d0 = fast_exp(soft_clip(r0, A1));
     const float d1 = fast_exp(soft_clip(r1, A1));
 
@@ -337,7 +424,9 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
     const float Q = 2.0f * s * z1 + d0 * omz * omz + d1 * z * z;
     const float jac = s * s * Q * iden * iden;
     y_out = inrange ? fmaf(hgt, R, y0) : x;
-    ladj_out = inrange ? logf(jac) : 0.0f;
+    // jac is a ratio of O(1) positive quantities (slopes in (1e-3, 1e3) squared at most): never denormal, so the bare
+    // v_log_f32 (log2, 1 ulp) times ln 2 replaces logf's denormal / infinity handling (12 instructions -> 2)
+    ladj_out = inrange ? __builtin_amdgcn_logf(jac) * 0.6931471805599453f : 0.0f;
 
     if (MODE == 1) {
         const float tz = 1.0f - 2.0f * z;
@@ -370,10 +459,12 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
         const float gcB = inrange ? 2.0f * RQS_BOUND * (hh ? gy1 : gx1) : 0.0f;
         const float dot = gcA * ck + gcB * ck1;
         // d/d(cumulative probability) reaches logit m through every knot >= m + 1: both knots (m < k), the upper one
-        // (m == k) or none; three candidates, two selects per logit
-        const float t_lt = (gcA + gcB) - dot, t_eq = gcB - dot, t_gt = 0.0f - dot;
+        // (m == k) or none; three candidates, two selects per logit.  pq holds the UNNORMALISED probability times
+        // (log2(e) * d soft_clip/dv): the normalisation and the constant ride on the three candidates.
+        const float nrm = inv * (1.0f / (LOG2E * LOG2E));
+        const float t_lt = ((gcA + gcB) - dot) * nrm, t_eq = (gcB - dot) * nrm, t_gt = (0.0f - dot) * nrm;
 #pragma unroll
-        for (int m = 0; m < K; ++m) g[m] = p[m] * ((m < k) ? t_lt : ((m == k) ? t_eq : t_gt)) * ia2[m];
+        for (int m = 0; m < K; ++m) g[m] = pq[m] * ((m < k) ? t_lt : ((m == k) ? t_eq : t_gt));
         const float gr0 = inrange ? Gd0 * d0 * soft_clip_grad(r0, A1) : 0.0f;
         const float gr1 = inrange ? Gd1 * d1 * soft_clip_grad(r1, A1) : 0.0f;
 #pragma unroll
@@ -588,34 +679,56 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_bwd_kernel(const float* __res
 __device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(size_t)p; }
 
 // group g: request the fragments of the group starting at k-step S4N into n[] (unconditionally: a skipped group's
-// fragments are never used), multiply-accumulate the four k-steps held in a[]
-template <int KS, int S4N>
+// fragments are never used), multiply-accumulate the four k-steps held in a[].
+// BA: the B operands (activations) are taken from AGPRs.  An MFMA reads A / B / C from either register file; an operand
+// constraint "v" on values that live across the VALU-heavy spline makes the compiler shuttle them between the files
+// (v_accvgpr_write to park, v_accvgpr_read to bring back: 64 VALU per 32-row tile and use), "a" lets them stay parked.
+#define MF_DEF_MFMA4(SUF, BC)                                                                                         \
+    template <int KS, int S4N>                                                                                        \
+    __device__ __forceinline__ void mfma4_pf_##SUF(f32x16_t& acc, const float (&a)[4], float (&n)[4], unsigned addr,  \
+                                                   float b0, float b1, float b2, float b3) {                          \
+        asm volatile(                                                                                                 \
+            "ds_read_b32 %1, %9 offset:%14\n\t"                                                                       \
+            "ds_read_b32 %2, %9 offset:%15\n\t"                                                                       \
+            "ds_read_b32 %3, %9 offset:%16\n\t"                                                                       \
+            "ds_read_b32 %4, %9 offset:%17\n\t"                                                                       \
+            "v_mfma_f32_32x32x2_f32 %0, %5, %10, %0\n\t"                                                              \
+            "v_mfma_f32_32x32x2_f32 %0, %6, %11, %0\n\t"                                                              \
+            "v_mfma_f32_32x32x2_f32 %0, %7, %12, %0\n\t"                                                              \
+            "v_mfma_f32_32x32x2_f32 %0, %8, %13, %0\n\t"                                                              \
+            "s_waitcnt lgkmcnt(0)"                                                                                    \
+            : "+v"(acc), "=&v"(n[0]), "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3])                                           \
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(addr), BC(b0), BC(b1), BC(b2), BC(b3),                  \
+              "n"(kcol(S4N) * KS * 4), "n"(kcol(S4N + 1) * KS * 4), "n"(kcol(S4N + 2) * KS * 4),                      \
+              "n"(kcol(S4N + 3) * KS * 4));                                                                           \
+    }                                                                                                                 \
+    /* last group of a chain: no prefetch */                                                                          \
+    __device__ __forceinline__ void mfma4_last_##SUF(f32x16_t& acc, const float (&a)[4], float b0, float b1, float b2, \
+                                                     float b3) {                                                      \
+        asm volatile(                                                                                                 \
+            "s_nop 1\n\t"                                                                                             \
+            "v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\t"                                                               \
+            "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"                                                               \
+            "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"                                                               \
+            "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"                                                                   \
+            : "+v"(acc)                                                                                               \
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), BC(b0), BC(b1), BC(b2), BC(b3));                            \
+    }
+#define MF_BC_V(x) "v"(x)
+#define MF_BC_A(x) "a"(x)
+MF_DEF_MFMA4(v, MF_BC_V)
+MF_DEF_MFMA4(a, MF_BC_A)
+#undef MF_DEF_MFMA4
+template <int KS, int S4N, bool BA = false>
 __device__ __forceinline__ void mfma4_pf(f32x16_t& acc, const float (&a)[4], float (&n)[4], unsigned addr, float b0, float b1,
                                          float b2, float b3) {
-    asm volatile(
-        "ds_read_b32 %1, %9 offset:%14\n\t"
-        "ds_read_b32 %2, %9 offset:%15\n\t"
-        "ds_read_b32 %3, %9 offset:%16\n\t"
-        "ds_read_b32 %4, %9 offset:%17\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %5, %10, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %6, %11, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %7, %12, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %8, %13, %0\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "+v"(acc), "=&v"(n[0]), "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3])
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(addr), "v"(b0), "v"(b1), "v"(b2), "v"(b3),
-          "n"(kcol(S4N) * KS * 4), "n"(kcol(S4N + 1) * KS * 4), "n"(kcol(S4N + 2) * KS * 4), "n"(kcol(S4N + 3) * KS * 4));
+    if constexpr (BA) mfma4_pf_a<KS, S4N>(acc, a, n, addr, b0, b1, b2, b3);
+    else mfma4_pf_v<KS, S4N>(acc, a, n, addr, b0, b1, b2, b3);
 }
-// last group of a chain: no prefetch
+template <bool BA = false>
 __device__ __forceinline__ void mfma4_last(f32x16_t& acc, const float (&a)[4], float b0, float b1, float b2, float b3) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
-        : "+v"(acc)
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    if constexpr (BA) mfma4_last_a(acc, a, b0, b1, b2, b3);
+    else mfma4_last_v(acc, a, b0, b1, b2, b3);
 }
 // the compiler cannot see the MFMAs inside the blocks: pad the MFMA -> VALU read distance (18 wait states) by hand
 __device__ __forceinline__ void mfma_drain(f32x16_t& acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
@@ -624,11 +737,19 @@ __device__ __forceinline__ void mfma_drain(f32x16_t& acc) { asm volatile("s_nop 
 
 // B operand accessors of a chain: k-step S of an accumulator pair, or of a 32-slot vector
 struct BTile {
+    static constexpr bool agpr = false;
+    const f32x16_t (&t)[2];
+    template <int S>
+    __device__ __forceinline__ float get() const { return t[S >> 4][S & 15]; }
+};
+struct BTileA {                          // the same, operands constrained to AGPRs (long-lived activations)
+    static constexpr bool agpr = true;
     const f32x16_t (&t)[2];
     template <int S>
     __device__ __forceinline__ float get() const { return t[S >> 4][S & 15]; }
 };
 struct BVec {
+    static constexpr bool agpr = false;
     const float (&v)[32];
     template <int S>
     __device__ __forceinline__ float get() const { return v[S]; }
@@ -647,7 +768,7 @@ __device__ __forceinline__ void chain64(f32x16_t& acc, const float* wl, int g0, 
         _Pragma("unroll") for (int j = 0; j < 4; ++j) CUR[j] = wl[kcol(4 * G + j) * KS];                              \
     }                                                                                                                 \
     if (G >= g0 && G < g1)                                                                                            \
-        mfma4_pf<KS, (4 * G + 4) & 31>(acc, CUR, NXT, addr, b.template get<4 * G>(), b.template get<4 * G + 1>(),     \
+        mfma4_pf<KS, (4 * G + 4) & 31, BOp::agpr>(acc, CUR, NXT, addr, b.template get<4 * G>(), b.template get<4 * G + 1>(), \
                                        b.template get<4 * G + 2>(), b.template get<4 * G + 3>());
     MF_GRP(0, a0, a1) MF_GRP(1, a1, a0) MF_GRP(2, a0, a1) MF_GRP(3, a1, a0) MF_GRP(4, a0, a1) MF_GRP(5, a1, a0) MF_GRP(6, a0, a1)
 #undef MF_GRP
@@ -656,7 +777,7 @@ __device__ __forceinline__ void chain64(f32x16_t& acc, const float* wl, int g0, 
         for (int j = 0; j < 4; ++j) a1[j] = wl[kcol(28 + j) * KS];
     }
     if (7 >= g0 && 7 < g1)
-        mfma4_last(acc, a1, b.template get<28>(), b.template get<29>(), b.template get<30>(), b.template get<31>());
+        mfma4_last<BOp::agpr>(acc, a1, b.template get<28>(), b.template get<29>(), b.template get<30>(), b.template get<31>());
     mfma_drain(acc);
 #else
 #define MF_STEP(S) if ((S) >= 4 * g0 && (S) < 4 * g1) acc = mfma(wl[kcol(S) * KS], b.template get<S>(), acc);
@@ -676,10 +797,10 @@ __device__ __forceinline__ void chain64(f32x16_t& acc, const float* wl, int g0, 
 template <int KS, int G, int NEXT_S, class BOp>     // NEXT_S: first k-step of the group to prefetch, -1: none
 __device__ __forceinline__ void chain_grp(f32x16_t& acc, const float (&cur)[4], float (&nxt)[4], unsigned addr_next, const BOp& b) {
     if constexpr (NEXT_S >= 0)
-        mfma4_pf<KS, NEXT_S>(acc, cur, nxt, addr_next, b.template get<4 * G>(), b.template get<4 * G + 1>(),
+        mfma4_pf<KS, NEXT_S, BOp::agpr>(acc, cur, nxt, addr_next, b.template get<4 * G>(), b.template get<4 * G + 1>(),
                              b.template get<4 * G + 2>(), b.template get<4 * G + 3>());
     else
-        mfma4_last(acc, cur, b.template get<4 * G>(), b.template get<4 * G + 1>(), b.template get<4 * G + 2>(),
+        mfma4_last<BOp::agpr>(acc, cur, b.template get<4 * G>(), b.template get<4 * G + 1>(), b.template get<4 * G + 2>(),
                    b.template get<4 * G + 3>());
 }
 #endif
@@ -722,47 +843,65 @@ __device__ __forceinline__ void chain64x2(f32x16_t& acc0, f32x16_t& acc1, const 
 // MFMAs are independent, which removes the ~3.5 cycles of issue stall a dependent fp32 MFMA pays
 // (tools/ubench_chain.hip: 64 MFMAs in 4445 instead of 4671 cycles).  Costs eight more fragment registers.
 #ifdef MF_ASM_CHAIN
-template <int KS, int S4N>
+#define MF_DEF_MFMA8(SUF, BC)                                                                                         \
+    template <int KS, int S4N>                                                                                        \
+    __device__ __forceinline__ void mfma8_pf_##SUF(f32x16_t& acc0, f32x16_t& acc1, const float (&a)[8], float (&n)[8], \
+                                                   unsigned addr0, unsigned addr1, float b0, float b1, float b2,      \
+                                                   float b3) {                                                        \
+        asm volatile(                                                                                                 \
+            "ds_read_b32 %2, %18 offset:%24\n\t"                                                                      \
+            "ds_read_b32 %3, %18 offset:%25\n\t"                                                                      \
+            "ds_read_b32 %4, %18 offset:%26\n\t"                                                                      \
+            "ds_read_b32 %5, %18 offset:%27\n\t"                                                                      \
+            "ds_read_b32 %6, %19 offset:%24\n\t"                                                                      \
+            "ds_read_b32 %7, %19 offset:%25\n\t"                                                                      \
+            "ds_read_b32 %8, %19 offset:%26\n\t"                                                                      \
+            "ds_read_b32 %9, %19 offset:%27\n\t"                                                                      \
+            "v_mfma_f32_32x32x2_f32 %0, %10, %20, %0\n\t"                                                             \
+            "v_mfma_f32_32x32x2_f32 %1, %14, %20, %1\n\t"                                                             \
+            "v_mfma_f32_32x32x2_f32 %0, %11, %21, %0\n\t"                                                             \
+            "v_mfma_f32_32x32x2_f32 %1, %15, %21, %1\n\t"                                                             \
+            "v_mfma_f32_32x32x2_f32 %0, %12, %22, %0\n\t"                                                             \
+            "v_mfma_f32_32x32x2_f32 %1, %16, %22, %1\n\t"                                                             \
+            "v_mfma_f32_32x32x2_f32 %0, %13, %23, %0\n\t"                                                             \
+            "v_mfma_f32_32x32x2_f32 %1, %17, %23, %1\n\t"                                                             \
+            "s_waitcnt lgkmcnt(0)"                                                                                    \
+            : "+v"(acc0), "+v"(acc1), "=&v"(n[0]), "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3]), "=&v"(n[4]), "=&v"(n[5]),   \
+              "=&v"(n[6]), "=&v"(n[7])                                                                                \
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(addr0),     \
+              "v"(addr1), BC(b0), BC(b1), BC(b2), BC(b3), "n"(kcol(S4N) * KS * 4), "n"(kcol(S4N + 1) * KS * 4),       \
+              "n"(kcol(S4N + 2) * KS * 4), "n"(kcol(S4N + 3) * KS * 4));                                              \
+    }                                                                                                                 \
+    __device__ __forceinline__ void mfma8_last_##SUF(f32x16_t& acc0, f32x16_t& acc1, const float (&a)[8], float b0,   \
+                                                     float b1, float b2, float b3) {                                  \
+        asm volatile(                                                                                                 \
+            "s_nop 1\n\t"                                                                                             \
+            "v_mfma_f32_32x32x2_f32 %0, %2, %10, %0\n\t"                                                              \
+            "v_mfma_f32_32x32x2_f32 %1, %6, %10, %1\n\t"                                                              \
+            "v_mfma_f32_32x32x2_f32 %0, %3, %11, %0\n\t"                                                              \
+            "v_mfma_f32_32x32x2_f32 %1, %7, %11, %1\n\t"                                                              \
+            "v_mfma_f32_32x32x2_f32 %0, %4, %12, %0\n\t"                                                              \
+            "v_mfma_f32_32x32x2_f32 %1, %8, %12, %1\n\t"                                                              \
+            "v_mfma_f32_32x32x2_f32 %0, %5, %13, %0\n\t"                                                              \
+            "v_mfma_f32_32x32x2_f32 %1, %9, %13, %1"                                                                  \
+            : "+v"(acc0), "+v"(acc1)                                                                                  \
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), BC(b0), BC(b1), \
+              BC(b2), BC(b3));                                                                                        \
+    }
+MF_DEF_MFMA8(v, MF_BC_V)
+MF_DEF_MFMA8(a, MF_BC_A)
+#undef MF_DEF_MFMA8
+template <int KS, int S4N, bool BA = false>
 __device__ __forceinline__ void mfma8_pf(f32x16_t& acc0, f32x16_t& acc1, const float (&a)[8], float (&n)[8], unsigned addr0,
                                          unsigned addr1, float b0, float b1, float b2, float b3) {
-    asm volatile(
-        "ds_read_b32 %2, %18 offset:%24\n\t"
-        "ds_read_b32 %3, %18 offset:%25\n\t"
-        "ds_read_b32 %4, %18 offset:%26\n\t"
-        "ds_read_b32 %5, %18 offset:%27\n\t"
-        "ds_read_b32 %6, %19 offset:%24\n\t"
-        "ds_read_b32 %7, %19 offset:%25\n\t"
-        "ds_read_b32 %8, %19 offset:%26\n\t"
-        "ds_read_b32 %9, %19 offset:%27\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %10, %20, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %1, %14, %20, %1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %11, %21, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %1, %15, %21, %1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %12, %22, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %1, %16, %22, %1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %13, %23, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %1, %17, %23, %1\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "+v"(acc0), "+v"(acc1), "=&v"(n[0]), "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3]), "=&v"(n[4]), "=&v"(n[5]), "=&v"(n[6]),
-          "=&v"(n[7])
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(addr0), "v"(addr1), "v"(b0),
-          "v"(b1), "v"(b2), "v"(b3), "n"(kcol(S4N) * KS * 4), "n"(kcol(S4N + 1) * KS * 4), "n"(kcol(S4N + 2) * KS * 4),
-          "n"(kcol(S4N + 3) * KS * 4));
+    if constexpr (BA) mfma8_pf_a<KS, S4N>(acc0, acc1, a, n, addr0, addr1, b0, b1, b2, b3);
+    else mfma8_pf_v<KS, S4N>(acc0, acc1, a, n, addr0, addr1, b0, b1, b2, b3);
 }
+template <bool BA = false>
 __device__ __forceinline__ void mfma8_last(f32x16_t& acc0, f32x16_t& acc1, const float (&a)[8], float b0, float b1, float b2,
                                            float b3) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %2, %10, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %1, %6, %10, %1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %3, %11, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %1, %7, %11, %1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %4, %12, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %1, %8, %12, %1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %5, %13, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %1, %9, %13, %1"
-        : "+v"(acc0), "+v"(acc1)
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    if constexpr (BA) mfma8_last_a(acc0, acc1, a, b0, b1, b2, b3);
+    else mfma8_last_v(acc0, acc1, a, b0, b1, b2, b3);
 }
 #endif
 template <int KS, int NG, class BOp>
@@ -779,11 +918,12 @@ __device__ __forceinline__ void chain64x2i(f32x16_t& acc0, f32x16_t& acc1, const
 #define MF_I(G, CUR, NXT)                                                                                             \
     if constexpr (G < NG) {                                                                                          \
         if constexpr (G + 1 < NG)                                                                                    \
-            mfma8_pf<KS, (4 * G + 4) & 31>(acc0, acc1, CUR, NXT, addr0, addr1, b.template get<4 * G>(),              \
+            mfma8_pf<KS, (4 * G + 4) & 31, BOp::agpr>(acc0, acc1, CUR, NXT, addr0, addr1, b.template get<4 * G>(),   \
                                            b.template get<4 * G + 1>(), b.template get<4 * G + 2>(),                 \
                                            b.template get<4 * G + 3>());                                             \
         else                                                                                                         \
-            mfma8_last(acc0, acc1, CUR, b.template get<4 * G>(), b.template get<4 * G + 1>(), b.template get<4 * G + 2>(), \
+            mfma8_last<BOp::agpr>(acc0, acc1, CUR, b.template get<4 * G>(), b.template get<4 * G + 1>(),               \
+                                  b.template get<4 * G + 2>(),                                                       \
                        b.template get<4 * G + 3>());                                                                 \
     }
     MF_I(0, a0, a1) MF_I(1, a1, a0) MF_I(2, a0, a1) MF_I(3, a1, a0) MF_I(4, a0, a1) MF_I(5, a1, a0) MF_I(6, a0, a1) MF_I(7, a1, a0)
@@ -882,97 +1022,123 @@ __device__ unsigned long long g_ws_diag[NUM_CU * 4 * 16];      // [workgroup][wa
 // so every wave keeps ONE accumulator block per stage (d last-layer blocks + L trunk levels: 9 x 16 registers for
 // d = 6, L = 3) for the whole kernel and stores it into the workgroup's slab row at the end (deterministic flush,
 // see dw_store), exactly like outer_accum_kernel.  Bias gradients are the row sums of S_A; the waves that share a row tile split the tiles.
-// Staged element (row, particle p) lives at row*32 + (((p >> 2) ^ (row >> 1)) & 7) * 4 + (p & 3): the 16-byte chunks
-// of a row are XOR-swizzled by row/2 so that both the producers' scalar writes (32 particles of one row, 32 banks) and the
-// consumers' ds_read_b128 (4 particles of one row per lane; 64 banks, 16-lane groups {0-3,12-15,20-27}, ...: the eight
-// even and the eight odd rows of a group must land on eight different 16-byte slots) are bank-conflict free without
-// padding.  LDS: trunk + COMPACT (and transposed) last-layer blocks (91 KB for d = 6) + 64 KB staging; d = 7 does not
-// fit and uses the two-kernel path.  With one wave per SIMD nothing hides an LDS or HBM round trip, so the MFMA chains
-// are hand-scheduled (chain64) and the particle rows of the next group are prefetched.
+// Staging layout: see FB_PS below (row pairs side by side, pair stride 66: one address register per tile and operand,
+// bank-conflict free for the producers' 64-float stores and the consumers' ds_read_b64).  LDS: trunk + COMPACT (and
+// transposed) last-layer blocks (91 KB for d = 6) + 66 KB staging; d = 7 does not fit and uses the two-kernel path.  With
+// one wave per SIMD nothing hides an LDS or HBM round trip, so the MFMA chains are hand-scheduled (chain64) and the
+// particle rows of the next group are prefetched.
 constexpr int FB_BLOCK = 256;
 constexpr int FB_DMAX = 6;
-constexpr int FB_TILE = 2048;
-
 // hidden columns block i keeps (its k-steps rounded up to groups of four, two columns per k-step)
 __device__ __forceinline__ int fb_blk_cols(const Sparsity& sp, int i) { return 2 * ((sp.kend3[i] + 3) & ~3); }
 
-// this lane's swizzled offsets: accumulator register r of lane (col, hh) is MFMA row (r&3) + 8(r>>2) + 4hh of its
-// 32-row tile, so ((row >> 1) & 7) = (4 ((r>>2) & 1) + (((r&3) + 4hh) >> 1)) & 7: eight variants, off[(r>>2)&1][r&3]
-struct StageLane {
-    int off[2][4];
-};
-__device__ __forceinline__ StageLane stage_lane(int col, int hh) {
-    StageLane s;
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int sw = (4 * e + ((j + 4 * hh) >> 1)) & 7;
-            s.off[e][j] = (((col >> 2) ^ sw) & 7) * 4 + (col & 3) + 32 * (j + 4 * hh);
-        }
-    return s;
-}
-__device__ __forceinline__ void stage_tile(float* S, const StageLane& sl, const f32x16_t (&a)[2]) {
+// Staged 64 x 32 tile: accumulator register r of row tile rt holds MFMA rows (r & 3) + 8 (r >> 2) + 4 hh for the two
+// lane halves hh; the two rows of such a PAIR sit side by side,
+//     element (pair 16 rt + r, half hh, particle col)  at  pair * FB_PS + 32 hh + col  =  pair * FB_PS + lane,
+// so a producer's store of one register is 64 consecutive floats: ONE address register (4 * lane) for the whole tile, every
+// other term an immediate, no bank conflict.  A consumer lane (row i of a 32-row tile, k-half kk) reads the 16 particles
+// 16 kk .. 16 kk + 15 of its row as eight ds_read_b64 at immediate offsets of ONE address; with the pair stride 66 the 32
+// rows of a tile start on 32 different even banks (2 r + 32 hh mod 64): conflict-free.  (r02 kept rows of 32 floats with
+// XOR-swizzled 16-byte chunks: also conflict-free, but eight swizzle registers for the producers and eight chunk
+// addresses per product for the consumers — loop invariants that the allocator spilled once the kernel ran at 512.)
+constexpr int FB_PS = 66;
+constexpr int FB_TILE = 32 * FB_PS;
+
+__device__ __forceinline__ void stage_tile(float* S, int lane, const f32x16_t (&a)[2]) {
+    float* q = S + lane;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[(32 * rt + 8 * (r >> 2)) * 32 + sl.off[(r >> 2) & 1][r & 3]] = a[rt][r];
+        for (int r = 0; r < 16; ++r) q[(16 * rt + r) * FB_PS] = a[rt][r];
 }
-__device__ __forceinline__ void stage_tile(float* S, const StageLane& sl, const float (&v)[32]) {
+__device__ __forceinline__ void stage_tile(float* S, int lane, const float (&v)[32]) {
+    float* q = S + lane;
 #pragma unroll
-    for (int m = 0; m < 32; ++m) S[(32 * (m >> 4) + 8 * ((m & 15) >> 2)) * 32 + sl.off[((m & 15) >> 2) & 1][m & 3]] = v[m];
+    for (int m = 0; m < 32; ++m) q[m * FB_PS] = v[m];
+}
+// rows 0 .. d-1 of a staged tile <- the particle rows x (lanes of half 0 write; row j = pair (j & 3), half (j >> 2))
+template <int DMAXR>
+__device__ __forceinline__ void stage_x_rows(float* S, int col, int hh, int d, const float (&xr)[DMAXR]) {
+    if (hh == 0) {
+#pragma unroll
+        for (int j = 0; j < DMAXR; ++j)
+            if (j < d) S[(j & 3) * FB_PS + 32 * (j >> 2) + col] = xr[j];
+    }
+}
+// float offset of (row i of row tile ra, particle 16 kk) within a staged tile
+__device__ __forceinline__ int stage_row_offset(int ra, int i, int kk) {
+    return (16 * ra + (i & 3) + 4 * (i >> 3)) * FB_PS + 32 * ((i >> 2) & 1) + 16 * kk;
 }
 
 struct DwFrag {
-    float4 a[4], b[4];
+    float2 a[8], b[8];
 };
-__device__ __forceinline__ void dw_load(DwFrag& f, const float* pa, const float* pb, const int (&co)[4]) {
+__device__ __forceinline__ void dw_load(DwFrag& f, const float* pa, const float* pb) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f.a[q] = *reinterpret_cast<const float4*>(pa + co[q]);
-        f.b[q] = *reinterpret_cast<const float4*>(pb + co[q]);
+    for (int q = 0; q < 8; ++q) {
+        f.a[q] = *reinterpret_cast<const float2*>(pa + 2 * q);
+        f.b[q] = *reinterpret_cast<const float2*>(pb + 2 * q);
     }
 }
 __device__ __forceinline__ void dw_mac(const DwFrag& f, bool mm, bool bias, f32x16_t& acc, float& bsum) {
     if (bias) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bsum += (f.a[q].x + f.a[q].y) + (f.a[q].z + f.a[q].w);
+        for (int q = 0; q < 8; ++q) bsum += f.a[q].x + f.a[q].y;
     }
     if (mm) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             acc = mfma(f.a[q].x, f.b[q].x, acc);
             acc = mfma(f.a[q].y, f.b[q].y, acc);
-            acc = mfma(f.a[q].z, f.b[q].z, acc);
-            acc = mfma(f.a[q].w, f.b[q].w, acc);
         }
     }
 }
 // acc += A[rows 32 ra ..][particles] * B[rows 32 rb ..][particles]^T over the staged tiles [t0, t0 + 2 npair);  bsum += row
 // sums of A over the tile pairs selected by bias_pair (-1: every pair; p: pair p only — the two waves that share a row
 // tile of a full product split its bias sums between them).  Two fragment sets ping-pong so that the reads of the next
-// tile are in flight during the MFMAs of this one.
+// tile are in flight during the MFMAs of this one.  (Compiler-scheduled form: the emulator build, and the gfx950 build
+// without MF_DW_ASM.)
 __device__ __forceinline__ void dw_accum(const float* SA, const float* SB, int ra, int rb, int t0, int npair, bool mm,
                                          int bias_pair, int lane, f32x16_t& acc, float& bsum) {
-    const int i = lane & 31, kk = lane >> 5, sw = (i >> 1) & 7;
-    const float* pa = SA + (32 * ra + i) * 32 + t0 * FB_TILE;
-    const float* pb = SB + (32 * rb + i) * 32 + t0 * FB_TILE;
-    int co[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) co[q] = ((4 * kk + q) ^ sw) * 4;
+    const int i = lane & 31, kk = lane >> 5;
+    const float* pa = SA + t0 * FB_TILE + stage_row_offset(ra, i, kk);
+    const float* pb = SB + t0 * FB_TILE + stage_row_offset(rb, i, kk);
     DwFrag f0, f1;
-    dw_load(f0, pa, pb, co);
+    dw_load(f0, pa, pb);
 #pragma unroll 1
     for (int u = 0; u < npair; ++u) {
         const bool bias = bias_pair < 0 || bias_pair == u;
-        dw_load(f1, pa + FB_TILE, pb + FB_TILE, co);
+        dw_load(f1, pa + FB_TILE, pb + FB_TILE);
         dw_mac(f0, mm, bias, acc, bsum);
-        if (u + 1 < npair) dw_load(f0, pa + 2 * FB_TILE, pb + 2 * FB_TILE, co);
+        if (u + 1 < npair) dw_load(f0, pa + 2 * FB_TILE, pb + 2 * FB_TILE);
         dw_mac(f1, mm, bias, acc, bsum);
         pa += 2 * FB_TILE;
         pb += 2 * FB_TILE;
     }
 }
+
+// ---- the same product, hand-scheduled (gfx950 build; -DMF_DW_COMPILER keeps the compiler-scheduled form for A/B) -------
+// The compiler's code for dw_accum costs a lone wave ~1.3 k cycles per product on top of its MFMAs (r02 ablation:
+// 40.8 k cycles for 26.6 k of matrix-pipe time): SLP-packed bias sums (v_pk_add_f32 fed by v_mov / v_accvgpr_read
+// shuffles) under exec-mask branches, address arithmetic per call, four waits per tile.  dw_product_asm.inc (generated by
+// tools/gen_dw_asm.py) holds ONE asm block per product shape: a ring of 8-byte fragment loads runs a few k-steps ahead
+// of the MFMAs, every pair of MFMAs waits for exactly its two loads (counted lgkmcnt; LDS returns in order), the bias row
+// sums are plain v_add_f32, nothing branches, and the only operands are the accumulator and ONE address per matrix.
+// Fragment registers are fixed physical registers (clobbers): ds_read_b64 fills 2-register tuples whose single registers
+// the MFMAs name, which operand constraints cannot express.
+#if defined(MF_ASM_CHAIN) && !defined(MF_DW_COMPILER)
+#define MF_DW_ASM 1
+#include "dw_product_asm.inc"
+// rows 32 ra.. of S_A times rows 32 rb.. of S_B over the tiles [t0, t0 + NT)
+template <int NT, int BIAS, bool MM>
+__device__ __forceinline__ void dw_product_at(const float* SA, const float* SB, int ra, int rb, int t0, int lane,
+                                              f32x16_t& acc, float& bsum) {
+    const int i = lane & 31, kk = lane >> 5;
+    const unsigned aa = lds_addr(SA + t0 * FB_TILE + stage_row_offset(ra, i, kk));
+    const unsigned ab = lds_addr(SB + t0 * FB_TILE + stage_row_offset(rb, i, kk));
+    dw_product<NT, BIAS, MM>(acc, bsum, aa, ab);
+}
+#endif
 
 // ---- deterministic flush of the per-workgroup parameter-gradient accumulators -------------------------------------
 // Every workgroup owns one ROW of a slab buffer gslab[rows][image floats] and writes its accumulator blocks there with
@@ -1078,7 +1244,6 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
-    const StageLane sl = stage_lane(col, hh);
     float* myA = SA + wid * FB_TILE;
     float* myB = SB + wid * FB_TILE;
     // product roles of this wave
@@ -1169,7 +1334,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         }
         WS_ACC(c_[0], t0_);
         FB_SYNC();                                   // the previous group's last product has read S_A / S_B
-        stage_tile(myB, sl, h[L - 1]);
+        stage_tile(myB, lane, h[L - 1]);
         // ---- output blocks: spline forward + adjoint, dL/dh_last, last-layer weight gradients
         f32x16_t gh[2];
         f32x16_t gacc;
@@ -1221,7 +1386,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             if (i > 0) FB_SYNC();                    // product i-1 has read S_A
             WS_ACC(c_[3], t0_);
             t0_ = WS_T();
-            stage_tile(myA, sl, gv);
+            stage_tile(myA, lane, gv);
             WS_ACC(c_[4], t0_);
             // gh += W3_i^T gphi_i BEFORE the meeting point of the product: the chain gives the four waves ~3 k cycles of
             // slack at barrier B, and gphi (32 registers) is dead by the time the product's fragments are live
@@ -1245,7 +1410,19 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 const int ra = full ? fra : hra, rb = full ? frb : 0;
                 const int t0 = full ? 0 : ht0, t1 = full ? 2 : 1;
                 const bool mm = kend3_i > 0;
+#if defined(MF_DW_ASM) && !defined(MF_FB_NO_DW)
+                (void)ra; (void)rb; (void)t0; (void)t1;
+                if (full) {                              // a full block always has a product (rt1 != 0 implies kend3 > 0)
+                    if (frb == 0) dw_product_at<4, 0x3, true>(SA, SB, fra, 0, 0, lane, accF, bsF);
+                    else dw_product_at<4, 0xc, true>(SA, SB, fra, 1, 0, lane, accF, bsF);
+                } else if (mm) {
+                    dw_product_at<2, 0x3, true>(SA, SB, hra, 0, ht0, lane, accF, bsF);
+                } else {
+                    dw_product_at<2, 0x3, false>(SA, SB, hra, 0, ht0, lane, accF, bsF);
+                }
+#else
                 FB_DW(SA, SB, ra, rb, t0, t1, mm, full ? frb : -1, lane, accF, bsF);
+#endif
                 WS_ACC(c_[6], t0_);
             }
         };
@@ -1281,12 +1458,21 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             t1_ = WS_T();
             if (l == 1) input_layer4(lds + g.offW0, lds + g.offB0, g.S0, xb, h[0], col, hh);
             FB_SYNC();                               // the previous product has read S_A / S_B
-            stage_tile(myA, sl, gh);
-            stage_tile(myB, sl, h[l - 1]);
+            stage_tile(myA, lane, gh);
+            stage_tile(myB, lane, h[l - 1]);
             FB_SYNC();
             WS_ACC(c_[12], t1_);
             t1_ = WS_T();
+#if defined(MF_DW_ASM) && !defined(MF_FB_NO_DW)
+            if (!(fra == 0 && frb == 1 && sp.kend_h[0] <= 16)) {
+                if (frb == 0) dw_product_at<4, 0x3, true>(SA, SB, fra, 0, 0, lane, accT[l], bsT[l]);
+                else dw_product_at<4, 0xc, true>(SA, SB, fra, 1, 0, lane, accT[l], bsT[l]);
+            } else {
+                dw_product_at<4, 0xc, false>(SA, SB, fra, 1, 0, lane, accT[l], bsT[l]);     // all-zero block: bias sums only
+            }
+#else
             FB_DW(SA, SB, fra, frb, 0, 2, !(fra == 0 && frb == 1 && sp.kend_h[0] <= 16), frb, lane, accT[l], bsT[l]);
+#endif
             WS_ACC(c_[13], t1_);
             t1_ = WS_T();
             f32x16_t t[2];
@@ -1317,14 +1503,14 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
 #pragma unroll
             for (int r = 0; r < 16; ++r) gh[rt][r] = (h[0][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
         FB_SYNC();
-        stage_tile(myA, sl, gh);
-        if (hh == 0) {                                     // S_B rows 0..d-1 <- x (rows >= d: stale finite values, never flushed)
-#pragma unroll
-            for (int j = 0; j < FB_DMAX; ++j)
-                if (j < d) myB[j * 32 + ((((col >> 2) ^ (j >> 1)) & 7) << 2) + (col & 3)] = xr[j];
-        }
+        stage_tile(myA, lane, gh);
+        stage_x_rows(myB, col, hh, d, xr);                  // S_B rows 0..d-1 <- x (rows >= d: stale finite values, never flushed)
         FB_SYNC();
+#if defined(MF_DW_ASM) && !defined(MF_FB_NO_DW)
+        dw_product_at<2, 0x3, true>(SA, SB, hra, 0, ht0, lane, accT[0], bsT[0]);
+#else
         FB_DW(SA, SB, hra, 0, ht0, 1, true, -1, lane, accT[0], bsT[0]);
+#endif
         WS_ACC(c_[15], t1_);
         WS_ACC(c_[9], t0_);
         t0_ = WS_T();
@@ -1792,7 +1978,6 @@ __global__ __launch_bounds__(FB_BLOCK) void affine_layer_bwd_fused_kernel(const 
     float* SA = lds + ((g.total + 3) & ~3);
     float* SB = SA + 4 * FB_TILE;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
-    const StageLane sl = stage_lane(col, hh);
     float* myA = SA + wid * FB_TILE;
     float* myB = SB + wid * FB_TILE;
     const int fra = wid >> 1, frb = wid & 1;              // full 64 x 64 product
@@ -1859,7 +2044,7 @@ __global__ __launch_bounds__(FB_BLOCK) void affine_layer_bwd_fused_kernel(const 
             if (L == 1) { h[0][0] = h0[0]; h[0][1] = h0[1]; }
         }
         __syncthreads();                                   // the previous group's last product has read S_A / S_B
-        stage_tile(myB, sl, h[L - 1]);
+        stage_tile(myB, lane, h[L - 1]);
         // ---- output block (row tile 0 only) and the affine adjoint
         const float* W3 = lds + g.offW3;
         f32x16_t phi = bias_tile(lds + g.offB3, 0, hh);
@@ -1886,7 +2071,7 @@ __global__ __launch_bounds__(FB_BLOCK) void affine_layer_bwd_fused_kernel(const 
                 for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
             }
         }
-        stage_tile(myA, sl, gv);
+        stage_tile(myA, lane, gv);
         __syncthreads();
         dw_accum(SA, SB, 0, frb, ht0, 1, true, frb == 0 ? -1 : 99, lane, accO, bsO);
         // gh = W3^T gphi: only the 16 slots of row tile 0 are populated (k-step groups 0..3)
@@ -1905,8 +2090,8 @@ __global__ __launch_bounds__(FB_BLOCK) void affine_layer_bwd_fused_kernel(const 
                 for (int r = 0; r < 16; ++r) gh[rt][r] = (h[l][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
             if (l == 1) input_layer4(lds + g.offW0, lds + g.offB0, g.S0, xb, h[0], col, hh);
             __syncthreads();
-            stage_tile(myA, sl, gh);
-            stage_tile(myB, sl, h[l - 1]);
+            stage_tile(myA, lane, gh);
+            stage_tile(myB, lane, h[l - 1]);
             __syncthreads();
             dw_accum(SA, SB, fra, frb, 0, 2, true, frb, lane, accT[l], bsT[l]);
             f32x16_t t[2];
@@ -1924,12 +2109,8 @@ __global__ __launch_bounds__(FB_BLOCK) void affine_layer_bwd_fused_kernel(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) gh[rt][r] = (h[0][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
         __syncthreads();
-        stage_tile(myA, sl, gh);
-        if (hh == 0) {
-#pragma unroll
-            for (int j = 0; j < DM; ++j)
-                if (j < d) myB[j * 32 + ((((col >> 2) ^ (j >> 1)) & 7) << 2) + (col & 3)] = xr[j];
-        }
+        stage_tile(myA, lane, gh);
+        stage_x_rows(myB, col, hh, d, xr);
         __syncthreads();
         dw_accum(SA, SB, hra, 0, ht0, 1, true, -1, lane, accT[0], bsT[0]);
         if (gx != nullptr) {

@@ -1,0 +1,127 @@
+"""ORACLE (test infrastructure) — N-chunked, two-pass evaluation of one MENTFlow.loss() + backward in fp64.
+
+Why: the dense restatement (oracle.model.train_step_loss) materialises every N x B kernel matrix and keeps the whole
+autograd graph — 29 GB at 100 000 particles and 100 projections — so it stops at ~50 000 particles, while BASELINE.json's
+configurations run 1 M .. 16 M.  The loss depends on the particles only through three sums,
+
+    S[p]    = sum_n K(u_np)            (1-D: [P, B];  2-D: Kx^T Ky, [P, Bx, By])       histogram.py:37-39, 69
+    s_logp  = sum_n log_prob_n,        s_prior = sum_n prior.log_prob(x_n)             entropy.py:58-62
+
+so the SAME arithmetic can be evaluated in bounded memory:
+
+    pass 1  (no grad)  per chunk of particles: x, log_prob = flow(z_chunk); accumulate S, s_logp, s_prior
+    tail    (autograd on the tiny tensors)   : L = H + mu * mean(D) as the reference normalises them
+                                               (histogram.py:39-43 / 69-73, loss.py:7-17, core.py:113-117);
+                                               backward gives gS = dL/dS, dL/ds_logp = 1/N, dL/ds_prior = -1/N
+    pass 2  (autograd) per chunk             : recompute the chunk with a graph, back-propagate the surrogate
+                                               <gS, S_chunk> + s_logp_chunk / N - s_prior_chunk / N;
+                                               parameter gradients add up over chunks (chain rule, exact).
+
+Every per-particle formula is the one of oracle.flow / oracle.kde / oracle.model (which cite the reference lines); nothing
+is truncated or approximated — only the order of the fp64 sums over particles changes.  ``tests/test_chunked_oracle.py``
+checks this file against oracle.harness.oracle_step (the dense oracle) at sizes where both run.
+
+Who may import it: tests/ and bench.py's cpu_baseline leg (see oracle/__init__.py).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import torch
+
+from . import flow as of
+from . import model as om
+from .harness import oracle_problem
+
+
+@dataclass
+class ChunkedResult:
+    L: torch.Tensor
+    H: torch.Tensor
+    D: List[torch.Tensor]
+    predictions: List[torch.Tensor]                 # normalised histograms, one per projection
+    grad: Optional[torch.Tensor] = None            # flat parameter gradient (oracle parameter order) or None
+    sums: dict = field(default_factory=dict)       # raw S, s_logp, s_prior (diagnostics)
+
+
+def _kernel_sums(u_rows, diag, dtype):
+    """Sum over the chunk of the reference's kernel values for ONE projection (diag = oracle.model.Histogram1D/2D)."""
+    if diag.ndim == 1:
+        xp = diag.project(u_rows)
+        res = xp.unsqueeze(-1) - diag.coords.to(dtype)                       # histogram.py:37
+        return torch.exp(-0.5 * (res / diag.bandwidth).pow(2)).sum(dim=0)    # :38, summed (the mean divides by N later)
+    xp = diag.project(u_rows)
+    cx = 0.5 * (diag.edges_x[:-1] + diag.edges_x[1:]).to(dtype)
+    cy = 0.5 * (diag.edges_y[:-1] + diag.edges_y[1:]).to(dtype)
+    kx = torch.exp(-0.5 * ((xp[:, 0:1] - cx) / diag.bandwidth_x).pow(2))
+    ky = torch.exp(-0.5 * ((xp[:, 1:2] - cy) / diag.bandwidth_y).pow(2))
+    return kx.transpose(-2, -1) @ ky                                         # histogram.py:69 (not divided by n)
+
+
+def _normalise(S, diag, n):
+    """Reference normalisation of the summed kernels (histogram.py:39-43 for 1-D, :69-73 for 2-D)."""
+    eps = 1.0e-10
+    if diag.ndim == 1:
+        prob = S / n                                                         # torch.mean over the particles (:39)
+        delta = diag.coords[1] - diag.coords[0]
+        return prob / (torch.sum(prob * delta) + eps)
+    cx = 0.5 * (diag.edges_x[:-1] + diag.edges_x[1:])
+    cy = 0.5 * (diag.edges_y[:-1] + diag.edges_y[1:])
+    dx, dy = cx[1] - cx[0], cy[1] - cy[0]                                    # joint_pdf uses the coordinate spacing (:70)
+    return S / (torch.sum(S * dx * dy) + eps)
+
+
+def chunked_step(prob, z: torch.Tensor, chunk: int = 8192, backward: bool = True, dtype=torch.float64,
+                 progress: Optional[Callable[[str], None]] = None) -> ChunkedResult:
+    """One MENTFlow.loss() (+ backward) of the problem `prob` (mentflow_amd.harness.Problem) with the base draw `z`
+    injected, evaluated chunk by chunk in `dtype`.  Memory ~ chunk x P x B x 8 bytes x a few."""
+    spec, transforms, diagnostics, measurements, prior, disc = oracle_problem(prob, dtype)
+    params = spec.parameters()
+    n = z.shape[0]
+    mu = float(prob.model.penalty_parameter)
+    diags = [row[0] for row in diagnostics]
+    meas = [row[0] for row in measurements]
+
+    def chunk_sums(zc):
+        x, logp = of.sample_and_log_prob(zc, spec)
+        S = [_kernel_sums(t(x.clone()), dg, dtype) for t, dg in zip(transforms, diags)]      # simulate.py:30-33
+        return S, logp.sum(), prior.log_prob(x).sum()
+
+    # ---- pass 1
+    S_tot, slogp, sprior = None, torch.zeros((), dtype=dtype), torch.zeros((), dtype=dtype)
+    with torch.no_grad():
+        for a in range(0, n, chunk):
+            S, lp, pr = chunk_sums(z[a:a + chunk].to(dtype))
+            S_tot = S if S_tot is None else [s0 + s1 for s0, s1 in zip(S_tot, S)]
+            slogp, sprior = slogp + lp, sprior + pr
+            if progress is not None and (a // chunk) % 16 == 0:
+                progress(f"chunked oracle pass 1: {a + chunk}/{n}")
+    # ---- tail on the reduced tensors
+    S_leaf = [s.clone().requires_grad_(backward) for s in S_tot]
+    slogp_l, sprior_l = slogp.clone().requires_grad_(backward), sprior.clone().requires_grad_(backward)
+    H = slogp_l / n - sprior_l / n                                                            # entropy.py:58-62
+    preds = [_normalise(s, dg, n) for s, dg in zip(S_leaf, diags)]
+    D = [disc(p_, m_) for p_, m_ in zip(preds, meas)]                                         # core.py:89-93
+    L = H + mu * (sum(D) / len(D))                                                            # core.py:116
+    res = ChunkedResult(L.detach(), H.detach(), [d.detach() for d in D], [p_.detach() for p_ in preds],
+                        sums={"S": S_tot, "s_logp": slogp, "s_prior": sprior})
+    if not backward:
+        return res
+    L.backward()
+    gS = [s.grad for s in S_leaf]
+    g_lp, g_pr = float(slogp_l.grad), float(sprior_l.grad)
+    # ---- pass 2
+    for p in params:
+        p.requires_grad_(True)
+        p.grad = None
+    for a in range(0, n, chunk):
+        S, lp, pr = chunk_sums(z[a:a + chunk].to(dtype))
+        sur = g_lp * lp + g_pr * pr
+        for s, g in zip(S, gS):
+            sur = sur + (s * g).sum()
+        sur.backward()
+        if progress is not None and (a // chunk) % 16 == 0:
+            progress(f"chunked oracle pass 2: {a + chunk}/{n}")
+    res.grad = torch.cat([p.grad.reshape(-1) for p in params]).detach()
+    return res
