@@ -1,6 +1,7 @@
 """MENT-Flow model — mirrors mentflow/core.py:18-161 (same constructor kwargs, attributes and return values)."""
 from __future__ import annotations
 
+import logging
 from typing import Callable, Iterator, List, Optional, Tuple
 
 import torch
@@ -15,6 +16,8 @@ from .loss import kl_divergence
 from .simulate import forward, group_measurements
 from .simulate.simulate import apply_pre
 from .utils import unravel
+
+log = logging.getLogger("mentflow_amd.core")
 
 
 class MENTFlow(nn.Module):
@@ -33,6 +36,7 @@ class MENTFlow(nn.Module):
         self.penalty_parameter = penalty_parameter
         self._plan = None
         self._plan_key = None
+        self._generic_logged = False
 
     def set_diagnostics(self, diagnostics):
         self.diagnostics = diagnostics
@@ -97,7 +101,9 @@ class MENTFlow(nn.Module):
                tuple((d.kde, d.noise and d.noise_scale > 0.0) for d in unravel(self.diagnostics)))
         if self._plan is not None and self._plan_key == key:
             return self._plan
-        groups = group_measurements(self.transforms, self.diagnostics)
+        groups, generic = group_measurements(self.transforms, self.diagnostics)
+        if generic:                      # a transport / diagnostic outside the fused kernels: the generic loop of loss()
+            return None
         order = {}
         pos = 0
         for i in range(len(self.transforms)):
@@ -121,8 +127,13 @@ class MENTFlow(nn.Module):
         parameter gradients identical to the single-GPU values (mentflow_amd/dist.py)."""
         plan = self._fused_plan()
         if plan is None:
+            # generic loop of the reference (core.py:113-117): any nn.Module transport, any diagnostic, any discrepancy
+            # callable; simulate.forward still takes the fused kernels for the pairs they cover
             if mfdist.is_active():
                 raise NotImplementedError("data-parallel loss needs the fused path (KDE histograms, kld/mae/mse)")
+            if not self._generic_logged:
+                self._generic_logged = True
+                log.info("MENTFlow.loss: generic path (sample -> simulate.forward -> discrepancy_function per measurement)")
             x, H = self.sample_and_entropy(batch_size)
             predictions = forward(x, self.transforms, self.diagnostics)
             D = self.discrepancy_vector(predictions)

@@ -461,10 +461,20 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
         // d/d(cumulative probability) reaches logit m through every knot >= m + 1: both knots (m < k), the upper one
         // (m == k) or none; three candidates, two selects per logit.  pq holds the UNNORMALISED probability times
         // (log2(e) * d soft_clip/dv): the normalisation and the constant ride on the three candidates.
+        // Written without compares: u_m = clamp(k - m, 0, 1) is 1 for m < k and 0 otherwise (one v_sub with the clamp
+        // modifier), "m == k" is u_{m-1} - u_m, so the factor is t_gt + u_m (t_lt - t_eq) + u_{m-1} (t_eq - t_gt): a
+        // subtract, two FMAs and the product per logit, no mask registers (a VALU compare followed by the select that
+        // reads its mask costs two wait states on gfx950, which the compiler fills with s_nop).
         const float nrm = inv * (1.0f / (LOG2E * LOG2E));
-        const float t_lt = ((gcA + gcB) - dot) * nrm, t_eq = (gcB - dot) * nrm, t_gt = (0.0f - dot) * nrm;
+        const float t_gt = (0.0f - dot) * nrm, d_eq = gcB * nrm, d_lt = gcA * nrm;   // t_eq - t_gt, t_lt - t_eq
+        const float kf = (float)k;
+        float u_prev = __builtin_amdgcn_fmed3f(kf + 1.0f, 0.0f, 1.0f);                // u_{-1}: k >= 0
 #pragma unroll
-        for (int m = 0; m < K; ++m) g[m] = pq[m] * ((m < k) ? t_lt : ((m == k) ? t_eq : t_gt));
+        for (int m = 0; m < K; ++m) {
+            const float u = __builtin_amdgcn_fmed3f(kf - (float)m, 0.0f, 1.0f);
+            g[m] = pq[m] * fmaf(u, d_lt, fmaf(u_prev, d_eq, t_gt));
+            u_prev = u;
+        }
         const float gr0 = inrange ? Gd0 * d0 * soft_clip_grad(r0, A1) : 0.0f;
         const float gr1 = inrange ? Gd1 * d1 * soft_clip_grad(r1, A1) : 0.0f;
 #pragma unroll
@@ -1129,14 +1139,26 @@ __device__ __forceinline__ void dw_accum(const float* SA, const float* SB, int r
 #if defined(MF_ASM_CHAIN) && !defined(MF_DW_COMPILER)
 #define MF_DW_ASM 1
 #include "dw_product_asm.inc"
-// rows 32 ra.. of S_A times rows 32 rb.. of S_B over the tiles [t0, t0 + NT)
-template <int NT, int BIAS, bool MM>
-__device__ __forceinline__ void dw_product_at(const float* SA, const float* SB, int ra, int rb, int t0, int lane,
-                                              f32x16_t& acc, float& bsum) {
+// This wave's share of one stage's product.  full: block (fra, frb) of a 64 x 64 product over all four tiles, bias row sums
+// from tile pair frb (the two waves of a row tile split them); otherwise block (hra, 0) of a one-column-tile product over
+// the wave's tile pair ht0, ht0 + 1 (mm = false: the block is all zero, only the bias sums are needed).
+struct DwRole {
+    int fra, frb, hra, ht0;
+};
+__device__ __forceinline__ void dw_product_stage(const float* SA, const float* SB, const DwRole& ro, bool full, bool mm, int lane,
+                                                 f32x16_t& acc, float& bsum) {
     const int i = lane & 31, kk = lane >> 5;
-    const unsigned aa = lds_addr(SA + t0 * FB_TILE + stage_row_offset(ra, i, kk));
-    const unsigned ab = lds_addr(SB + t0 * FB_TILE + stage_row_offset(rb, i, kk));
-    dw_product<NT, BIAS, MM>(acc, bsum, aa, ab);
+    if (full) {
+        const int t1 = 2 * ro.frb, t2 = 2 - t1;
+        const unsigned oa = lds_addr(SA + stage_row_offset(ro.fra, i, kk)), ob = lds_addr(SB + stage_row_offset(ro.frb, i, kk));
+        if (mm) dw_product_full(acc, bsum, oa + t1 * FB_TILE * 4, ob + t1 * FB_TILE * 4, oa + t2 * FB_TILE * 4, ob + t2 * FB_TILE * 4);
+        else dw_product_bias(acc, bsum, oa + t1 * FB_TILE * 4, ob);
+    } else {
+        const unsigned oa = lds_addr(SA + ro.ht0 * FB_TILE + stage_row_offset(ro.hra, i, kk));
+        const unsigned ob = lds_addr(SB + ro.ht0 * FB_TILE + stage_row_offset(0, i, kk));
+        if (mm) dw_product_half(acc, bsum, oa, ob);
+        else dw_product_bias(acc, bsum, oa, ob);
+    }
 }
 #endif
 
@@ -1249,6 +1271,9 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
     // product roles of this wave
     const int fra = wid >> 1, frb = wid & 1;              // full 64 x 64 product
     const int hra = wid & 1, ht0 = 2 * (wid >> 1);        // single column tile, k split over tile pairs
+#ifdef MF_DW_ASM
+    const DwRole role{fra, frb, hra, ht0};
+#endif
 
     f32x16_t accO[FB_DMAX], accT[L];
     float bsO[FB_DMAX], bsT[L];
@@ -1407,29 +1432,20 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             t0_ = WS_T();
             {
                 const bool full = rt1_i != 0;
-                const int ra = full ? fra : hra, rb = full ? frb : 0;
-                const int t0 = full ? 0 : ht0, t1 = full ? 2 : 1;
                 const bool mm = kend3_i > 0;
 #if defined(MF_DW_ASM) && !defined(MF_FB_NO_DW)
-                (void)ra; (void)rb; (void)t0; (void)t1;
-                if (full) {                              // a full block always has a product (rt1 != 0 implies kend3 > 0)
-                    if (frb == 0) dw_product_at<4, 0x3, true>(SA, SB, fra, 0, 0, lane, accF, bsF);
-                    else dw_product_at<4, 0xc, true>(SA, SB, fra, 1, 0, lane, accF, bsF);
-                } else if (mm) {
-                    dw_product_at<2, 0x3, true>(SA, SB, hra, 0, ht0, lane, accF, bsF);
-                } else {
-                    dw_product_at<2, 0x3, false>(SA, SB, hra, 0, ht0, lane, accF, bsF);
-                }
+                dw_product_stage(SA, SB, role, full, mm, lane, accF, bsF);
 #else
-                FB_DW(SA, SB, ra, rb, t0, t1, mm, full ? frb : -1, lane, accF, bsF);
+                FB_DW(SA, SB, full ? fra : hra, full ? frb : 0, full ? 0 : ht0, full ? 2 : 1, mm, full ? frb : -1, lane, accF, bsF);
 #endif
                 WS_ACC(c_[6], t0_);
             }
         };
         // The feature loop stays rolled (the spline is ~8 KB of code), so the accumulator of "the current feature"
         // cannot be indexed by i: two features per iteration use accO[0] and accO[1], then the array is rotated by two
-        // (register moves; FB_DMAX / 2 iterations bring every block back to its place).  A switch on i made the
-        // register allocator copy all six blocks at every merge; rotating after every feature cost twice the moves.
+        // (register moves; FB_DMAX / 2 iterations bring every block back to its place).  A switch on i whose cases name
+        // accO[0..5] removes the 96 moves per pair but costs more than it saves (r03: +290 scalar instructions per group
+        // for the dispatch, 17.46 ms against 17.27 per step); rotating after every feature cost twice the moves.
         static_assert(FB_DMAX % 2 == 0, "two features per iteration");
 #pragma unroll 1
         for (int i = 0; i < FB_DMAX; i += 2) {
@@ -1464,12 +1480,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             WS_ACC(c_[12], t1_);
             t1_ = WS_T();
 #if defined(MF_DW_ASM) && !defined(MF_FB_NO_DW)
-            if (!(fra == 0 && frb == 1 && sp.kend_h[0] <= 16)) {
-                if (frb == 0) dw_product_at<4, 0x3, true>(SA, SB, fra, 0, 0, lane, accT[l], bsT[l]);
-                else dw_product_at<4, 0xc, true>(SA, SB, fra, 1, 0, lane, accT[l], bsT[l]);
-            } else {
-                dw_product_at<4, 0xc, false>(SA, SB, fra, 1, 0, lane, accT[l], bsT[l]);     // all-zero block: bias sums only
-            }
+            dw_product_stage(SA, SB, role, true, !(fra == 0 && frb == 1 && sp.kend_h[0] <= 16), lane, accT[l], bsT[l]);
 #else
             FB_DW(SA, SB, fra, frb, 0, 2, !(fra == 0 && frb == 1 && sp.kend_h[0] <= 16), frb, lane, accT[l], bsT[l]);
 #endif
@@ -1507,7 +1518,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         stage_x_rows(myB, col, hh, d, xr);                  // S_B rows 0..d-1 <- x (rows >= d: stale finite values, never flushed)
         FB_SYNC();
 #if defined(MF_DW_ASM) && !defined(MF_FB_NO_DW)
-        dw_product_at<2, 0x3, true>(SA, SB, hra, 0, ht0, lane, accT[0], bsT[0]);
+        dw_product_stage(SA, SB, role, false, true, lane, accT[0], bsT[0]);
 #else
         FB_DW(SA, SB, hra, 0, ht0, 1, true, -1, lane, accT[0], bsT[0]);
 #endif

@@ -1,12 +1,17 @@
 """Forward simulation of the measurement set — mirrors mentflow/simulate/simulate.py:8-47.
 
 The reference loops over transforms in Python (``u = transform(x.clone())`` then each diagnostic).  Here every
-(transform, diagnostic) pair of a measurement set that is ``LinearTransform`` + ``Histogram1D/2D`` is reduced to its
-projection row(s) ``matrix[axis]`` and all pairs that share a diagnostic object are evaluated by ONE fused
-projection + KDE launch; the list-of-lists result has the same structure and values as the reference's.
+(transform, diagnostic) pair of a measurement set that is ``LinearTransform`` (optionally behind a ``CompositeTransform`` of
+pre-transforms) + ``Histogram1D/2D`` is reduced to its projection row(s) ``matrix[axis]`` and all pairs that share a
+diagnostic object are evaluated by ONE fused projection + KDE launch (the fast path).  Any other pair — a transport that is
+not of that form (e.g. a kick applied AFTER the rotation), any other ``nn.Module`` transport, a ``Projection`` or user
+diagnostic — takes the reference's generic loop: the transform is applied as given and the diagnostic is called on the
+result (``Histogram*.forward(u)`` still runs the HIP kernels, with identity projection rows).  The list-of-lists result has
+the same structure and values as the reference's either way; which path a measurement set takes is logged once.
 """
 from __future__ import annotations
 
+import logging
 from typing import Dict, List, Tuple
 
 import torch
@@ -14,6 +19,9 @@ import torch.nn as nn
 
 from ..diagnostics import Histogram
 from .transform import CompositeTransform, LinearTransform
+
+log = logging.getLogger("mentflow_amd.simulate")
+_logged_plans = set()
 
 
 def split_transform(transform):
@@ -32,21 +40,24 @@ def split_transform(transform):
 
 
 def group_measurements(transforms, diagnostics):
-    """{(id(diagnostic), pre chain): (diagnostic, pre, [(i, j) slots], [projection rows])} for the fused path; raises for
-    anything the fused kernels do not cover (nothing silently falls back to eager torch).  All (transform, diagnostic)
-    pairs that share a diagnostic object and the same pre-transform chain are evaluated by one kernel launch."""
-    groups = {}
+    """(groups, generic): groups = {(id(diagnostic), pre chain): (diagnostic, pre, [(i, j) slots], [projection rows])} for
+    the fused path — all (transform, diagnostic) pairs that share a diagnostic object and the same pre-transform chain are
+    evaluated by one kernel launch; generic = the (i, j) slots the fused kernels do not cover (simulate.py:30-33 loop)."""
+    groups, generic = {}, []
     for i, transform in enumerate(transforms):
-        pre, linear = split_transform(transform)
+        try:
+            pre, linear = split_transform(transform)
+        except NotImplementedError:
+            pre, linear = (), None
         for j, diagnostic in enumerate(diagnostics[i]):
-            if not isinstance(diagnostic, Histogram):
-                raise NotImplementedError(
-                    f"{type(diagnostic).__name__}: only Histogram1D/Histogram2D diagnostics are on the hot path")
+            if linear is None or not isinstance(diagnostic, Histogram):
+                generic.append((i, j))
+                continue
             key = (id(diagnostic), tuple(id(t) for t in pre))
             entry = groups.setdefault(key, (diagnostic, pre, [], []))
             entry[2].append((i, j))
             entry[3].append(diagnostic.projection_rows(linear.matrix))
-    return groups
+    return groups, generic
 
 
 def apply_pre(x: torch.Tensor, pre) -> torch.Tensor:
@@ -55,14 +66,33 @@ def apply_pre(x: torch.Tensor, pre) -> torch.Tensor:
     return x
 
 
+def _log_plan(transforms, diagnostics, groups, generic) -> None:
+    key = (tuple(id(t) for t in transforms), tuple(id(d) for row in diagnostics for d in row))
+    if key in _logged_plans:
+        return
+    _logged_plans.add(key)
+    n_fused = sum(len(g[2]) for g in groups.values())
+    log.info("simulate.forward: %d measurement(s) on the fused projection + KDE path (%d launch group(s)), %d on the "
+             "generic transform -> diagnostic loop%s", n_fused, len(groups), len(generic),
+             "" if not generic else " " + str([(type(transforms[i]).__name__, type(diagnostics[i][j]).__name__)
+                                               for i, j in generic[:4]]))
+
+
 def forward(x: torch.Tensor, transforms: List[nn.Module], diagnostics: List[List[nn.Module]]) -> List[List[torch.Tensor]]:
     """simulate.py:8-33: predictions[i][j] = diagnostics[i][j](transforms[i](x))."""
     predictions: List[List[torch.Tensor]] = [[None] * len(diagnostics[i]) for i in range(len(transforms))]
-    for diagnostic, pre, slots, rows in group_measurements(transforms, diagnostics).values():
+    groups, generic = group_measurements(transforms, diagnostics)
+    _log_plan(transforms, diagnostics, groups, generic)
+    for diagnostic, pre, slots, rows in groups.values():
         stacked = [torch.stack([r[k] for r in rows]) for k in range(len(rows[0]))]
         hists = diagnostic.batched(apply_pre(x, pre), stacked)
         for (i, j), h in zip(slots, hists.unbind(0)):
             predictions[i][j] = diagnostic._apply_noise(h)
+    transported: Dict[int, torch.Tensor] = {}
+    for i, j in generic:                                  # the reference's loop, one transform application per i
+        if i not in transported:
+            transported[i] = transforms[i](x.clone())     # simulate.py:32 (a user transform may work in place)
+        predictions[i][j] = diagnostics[i][j](transported[i])
     return predictions
 
 

@@ -76,6 +76,22 @@ def chunked_step(prob, z: torch.Tensor, chunk: int = 8192, backward: bool = True
                  progress: Optional[Callable[[str], None]] = None) -> ChunkedResult:
     """One MENTFlow.loss() (+ backward) of the problem `prob` (mentflow_amd.harness.Problem) with the base draw `z`
     injected, evaluated chunk by chunk in `dtype`.  Memory ~ chunk x P x B x 8 bytes x a few."""
+    import os
+    # the GPU box reports every core of its host while the job owns 16: an OpenMP pool of os.cpu_count() threads is
+    # oversubscribed several times over and the small fp64 kernels of this file crawl (4 min for 2 M particles against 40 s)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(ncpu, 16)))
+    try:
+        return _chunked_step(prob, z, chunk, backward, dtype, progress)
+    finally:
+        torch.set_num_threads(old_threads)
+
+
+def _chunked_step(prob, z, chunk, backward, dtype, progress) -> ChunkedResult:
     spec, transforms, diagnostics, measurements, prior, disc = oracle_problem(prob, dtype)
     params = spec.parameters()
     n = z.shape[0]

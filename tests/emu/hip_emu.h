@@ -260,5 +260,6 @@ static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(fmaxf(a, b), c), fminf(a, b)); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); }
 static inline float fminf_(float a, float b) { return a < b ? a : b; }

@@ -44,6 +44,12 @@ def _gpu():
     return torch.device("cuda", 0)
 
 
+def _progress(msg):
+    """A line per 16 chunks on the real stdout: a GPU-box run that stays silent for minutes is taken to be hung."""
+    import sys
+    print("  " + msg, file=sys.__stdout__, flush=True)
+
+
 def _forward_vs_chunked(prob, n, dev, chunk, label):
     """Forward quantities of one loss() at n particles against the chunked fp64 oracle.  Gates = the small-batch ones
     (tests/test_baseline_configs.py): H 2e-5 rel, D 2e-4 rel, L 1e-4 + mu 2e-6, histograms rtol 2e-5 + atol 1e-6."""
@@ -59,7 +65,7 @@ def _forward_vs_chunked(prob, n, dev, chunk, label):
         preds = [row[0] for row in mf.simulate.forward(x, prob.transforms, prob.diagnostics)]
     torch.cuda.synchronize()
     t1 = time.time()
-    r = chunked_step(prob, z, chunk=chunk, backward=False)
+    r = chunked_step(prob, z, chunk=chunk, backward=False, progress=_progress)
     t2 = time.time()
     mu = float(prob.model.penalty_parameter)
     Dk, Dr = torch.stack(D).cpu().double(), torch.stack(r.D)
@@ -104,7 +110,7 @@ def _grads_vs_chunked(prob, n, dev, chunk, label, gtol=5e-4):
     L.backward()
     gk = torch.cat([p.grad.reshape(-1) for p in prob.model.parameters()]).cpu().double()
     t0 = time.time()
-    r = chunked_step(prob, z, chunk=chunk, backward=True)
+    r = chunked_step(prob, z, chunk=chunk, backward=True, progress=_progress)
     mu = float(prob.model.penalty_parameter)
     eg = float((gk - r.grad).abs().max() / r.grad.abs().max())
     eL = abs(float(L.detach()) - float(r.L))

@@ -147,12 +147,16 @@ def test_corner_and_rotation_optics_equal_reference():
         assert abs(float(a @ a) - 1) < 1e-6 and abs(float(b @ b) - 1) < 1e-6 and abs(float(a @ b)) < 1e-6
 
 
-def test_group_measurements_rejects_what_is_not_fused():
+def test_group_measurements_sends_what_is_not_fused_to_the_generic_loop():
     diag = mf.diagnostics.Histogram1D(edges=torch.linspace(-1, 1, 9))
-    with pytest.raises(NotImplementedError):
-        mf.simulate.group_measurements([torch.nn.Identity()], [[diag]])
-    with pytest.raises(NotImplementedError):
-        mf.simulate.group_measurements([mf.simulate.LinearTransform(torch.eye(2))], [[mf.diagnostics.Projection(0)]])
+    lin = mf.simulate.LinearTransform(torch.eye(2))
+    groups, generic = mf.simulate.group_measurements([torch.nn.Identity()], [[diag]])
+    assert not groups and generic == [(0, 0)]                      # an arbitrary nn.Module transport
+    groups, generic = mf.simulate.group_measurements([lin], [[mf.diagnostics.Projection(0)]])
+    assert not groups and generic == [(0, 0)]                      # a non-histogram diagnostic
+    kick_last = mf.simulate.CompositeTransform(lin, mf.simulate.MultipoleTransform(order=3, strength=0.5))
+    groups, generic = mf.simulate.group_measurements([lin, kick_last], [[diag, mf.diagnostics.Projection(1)], [diag]])
+    assert len(groups) == 1 and list(groups.values())[0][2] == [(0, 0)] and generic == [(0, 1), (1, 0)]
     # direction projections fold the transport matrix into the projection row
     d2 = mf.diagnostics.Histogram1D(edges=torch.linspace(-1, 1, 9), direction=torch.tensor([3.0, 4.0]))
     M = torch.tensor([[0.0, 1.0], [1.0, 0.0]])
