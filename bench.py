@@ -80,6 +80,8 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--per-gpu", type=int, default=None, help="particles per GPU (overrides the scaling mode's batch)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="with --scaling strong: the global particle count divided over the ranks (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--bwd-chunk", type=int, default=None, help="particles per flow-backward chunk (tuning)")
@@ -379,7 +381,9 @@ def run_worker(args) -> int:
     if args.per_gpu:
         per_gpu, global_batch = args.per_gpu, args.per_gpu * world
     elif args.scaling == "strong":
-        global_batch = strong_global
+        global_batch = args.global_batch or strong_global
+        if global_batch % world:
+            raise SystemExit(f"--scaling strong: the global batch {global_batch} is not divisible by {world} ranks")
         per_gpu = global_batch // world
     else:
         per_gpu, global_batch = weak_per_gpu, weak_per_gpu * world

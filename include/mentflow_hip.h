@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 2
+#define MF_ABI_VERSION 3
 #define MF_ENTROPY_SCRATCH_DOUBLES 2048
 
 int mf_abi_version(void);
@@ -68,6 +68,15 @@ int mf_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, i
  *       floats per particle for the hand-off to the parameter-gradient kernel (callers then process the batch in
  *       chunks to bound it).                                                                                    */
 int64_t mf_flow_image_floats(int d, int hidden_layers);
+/* Spline bins: 20 (the reference's value, experiments/setup.py:119-121) and 8 (zuko's default) are compile-time instances;
+ * every other 2 <= bins <= 21 runs through a run-time instance whose last-layer block is laid out for 21 bins.  Returns the
+ * slot (0..31) of a lane half's first derivative logit in the packed block — `bins` for the compile-time instances, 21
+ * for the run-time one — or -1 if there is no kernel for that number of bins (the packer needs it: packing.py).        */
+int mf_flow_rqs_deriv_slot(int bins);
+/* Backward variant of the flow layers: -1 = default (environment variable MENTFLOW_BWD_FUSED, read once; unset = fused),
+ * 0 = two-kernel path (backward + parameter-gradient contraction through an HBM scratch), 1 = fused kernel.  Process-wide;
+ * tests use it to run both variants in one process.                                                                */
+int mf_flow_set_bwd_variant(int variant);
 int64_t mf_flow_bwd_scratch_floats(int64_t n, int d, int hidden_layers, const int32_t* order);
 int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
                           const float* x, int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp,
@@ -112,7 +121,10 @@ int mf_flow_affine_layer_inv(const float* image, int d, int hidden_layers, const
  *   normalisation of histogram.py:39-43 happen in mf_hist_norm_discrepancy_fwd, after any cross-GPU sum)
  * Only the 2*radius+1 bins around each projected particle are visited (dropped kernel values are below
  * exp(-(radius+1/2)^2 delta^2 / (2 sigma^2)), 3e-18 for the reference's sigma = delta/2 and radius 4); pass
- * radius >= B for the dense sum.                                                                              */
+ * radius >= B for the dense sum.  radius and sigma are independent arguments: every pair is evaluated correctly.
+ * (radius = 4 with delta / sigma in [2, 2.6] — the reference's bandwidths 0.39 .. 0.5 bins — takes a specialised window
+ * with factorised tail weights and, in 2-D, without the 12 corner cells whose weight is below the 2^-50 quantum for
+ * every position of the particle; the kernels test the ratio themselves and run the plain loop otherwise.)       */
 /* ws: mf_proj_kde_ws_bytes(P, bins) bytes of scratch: one 64-bit INTEGER accumulator per bin.
  * Weights are summed as fixed-point integers at every level (2^-50 units with 64-bit LDS atomics inside a workgroup,
  * one 64-bit integer global atomic per bin and workgroup in 2^(s-50) units, s = max(0, ceil(log2 n) - 13): exact up to

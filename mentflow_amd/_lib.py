@@ -30,6 +30,8 @@ PROTOTYPES = {
     "mf_prof_report": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mf_gather_f32": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _ptr]),
     "mf_flow_image_floats": (_i64, [_i32, _i32]),
+    "mf_flow_rqs_deriv_slot": (_i32, [_i32]),
+    "mf_flow_set_bwd_variant": (_i32, [_i32]),
     "mf_flow_bwd_scratch_floats": (_i64, [_i64, _i32, _i32, _ptr]),
     "mf_flow_rqs_layer_fwd": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32, _ptr]),
     "mf_flow_bwd_slab_rows": (_i32, [_i64, _i32, _i32, _ptr]),
@@ -83,7 +85,7 @@ def use_library(path: str) -> None:
     """Load a specific build of the C-ABI library (tests only)."""
     global _lib, _device_type
     lib = _bind(C.CDLL(path))
-    if lib.mf_abi_version() != 2:
+    if lib.mf_abi_version() != 3:
         raise LibraryError(f"ABI version mismatch in {path}")
     _lib = lib
     _device_type = "cpu" if lib.mf_is_emulation() else "cuda"
@@ -98,6 +100,11 @@ def get_lib() -> C.CDLL:
             )
         use_library(DEFAULT_PATH)
     return _lib
+
+
+def set_flow_bwd_variant(variant=None) -> None:
+    """None: default (MENTFLOW_BWD_FUSED read once, unset = fused); False: two-kernel backward; True: fused backward."""
+    call("mf_flow_set_bwd_variant", -1 if variant is None else int(bool(variant)))
 
 
 def device_type() -> str:

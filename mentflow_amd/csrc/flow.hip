@@ -322,32 +322,42 @@ __device__ __forceinline__ void select_pair(const T (&t)[N + 1], int idx, T& lo,
 // rounding" the double accumulator gives, for 5 full-rate instructions per bin (fma, cvt, add, compare, add-carry) instead
 // of the 44 cycles of cvt_f64 / add_f64 / cvt_f32.  The bin search compares the integer prefixes with the (exactly
 // converted) query, so it is a total order consistent with the knots that are then used.
+// K > 0: bins known at compile time (the built fast instances: 8 and 20).  K == RQS_ANY: any 2 <= bins <= 21 at run time
+// (`kbins`), for configurations outside the fast instances (experiments/setup.py:119-121 takes bins from the config): the
+// slots are laid out for the maximum — logits in slots 0..20 (slots >= bins unused), derivatives from slot 21 — and the
+// loops over 21 bins mask the unused ones.  Slower (all 21 iterations run), same arithmetic.
+constexpr int RQS_ANY = -1;
+constexpr int RQS_KMAX = 21;
 template <int K, int MODE>
 __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh, float& y_out, float& ladj_out,
-                                          float gy, float gl, float (&g)[32], float& gx_out) {
-    constexpr int KD0 = K / 2;            // derivatives owned by half 0 (interior knots 1..KD0)
-    constexpr int KD1 = K - 1 - KD0;      // derivatives owned by half 1
+                                          float gy, float gl, float (&g)[32], float& gx_out, int kbins = 0) {
+    constexpr int KM = K > 0 ? K : RQS_KMAX;                   // loop / table bound; derivative slots start at KM
+    constexpr int KD0M = KM / 2;                               // table bound of the derivatives per half
+    const int kb = K > 0 ? K : kbins;                          // bins
+    const int KD0 = kb / 2;               // derivatives owned by half 0 (interior knots 1..KD0)
+    const int KD1 = kb - 1 - KD0;         // derivatives owned by half 1
     constexpr float A2 = 2.0f * LOG_SLOPE_INV;
     constexpr float A1 = LOG_SLOPE_INV;
     constexpr float FIX = 2147483648.0f;  // 2^31: prefix sums <= 1 + 20 * 2^-32 fit 32 bits with headroom
-    static_assert(K + KD0 <= 32, "spline does not fit the 32 slots of a lane half");
+    static_assert(KM + KD0M <= 32, "spline does not fit the 32 slots of a lane half");
+#define MF_BIN_ON(m) (K > 0 || (m) < kb)
 
     // soft clip + softmax over this half's K logits.  The clipped logits lie in (-3.46, 3.46), so exp() cannot
     // overflow and the usual max subtraction (a no-op mathematically) is not needed.  log2(e) is folded into the
     // reciprocal: ia = log2(e) / (1 + |v| A2), p = exp2(v * ia).  The adjoint needs d soft_clip / dv = (ia / log2 e)^2:
     // pq = p * ia^2 is formed here, the constant joins the three per-feature factors below.
-    float p[K], pq[MODE == 1 ? K : 1];
+    float p[KM], pq[MODE == 1 ? KM : 1];
     float sum = 0.0f;
 #pragma unroll
-    for (int m = 0; m < K; ++m) {
+    for (int m = 0; m < KM; ++m) {
         const float ia = fast_rcp(fmaf(fabsf(v[m]), A2 / LOG2E, 1.0f / LOG2E));
-        p[m] = __builtin_amdgcn_exp2f(v[m] * ia);
+        p[m] = MF_BIN_ON(m) ? __builtin_amdgcn_exp2f(v[m] * ia) : 0.0f;
         if (MODE == 1) pq[m] = p[m] * (ia * ia);
         sum += p[m];
     }
     const float inv = fast_rcp(sum);
     // bin search on the cumulative probabilities:  knot_j < x  <=>  c_j < (x / bound + 1) / 2
-    unsigned cj[K + 1];
+    unsigned cj[KM + 1];
     cj[0] = 0u;
     const float xc = fmaf(x, 0.5f / RQS_BOUND, 0.5f);
     const unsigned xq = cvt_u32_sat(xc * FIX);          // exact for 0 <= xc < 2 (a power-of-two scaling), saturating outside
@@ -355,10 +365,10 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
     unsigned c = 0u;
     int cnt = (-RQS_BOUND < x) ? 1 : 0;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
+    for (int j = 0; j < KM; ++j) {
         c += cvt_u32_sat(fmaf(p[j], fscale, 0.5f));
         cj[j + 1] = c;
-        cnt += (c < xq) ? 1 : 0;
+        cnt += (MF_BIN_ON(j) && c < xq) ? 1 : 0;
     }
     {   // both lanes use the count of the half that owns the searched knots: widths (half 0), heights for the inverse
         int lo, hi;
@@ -366,9 +376,9 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
         cnt = (MODE == 2) ? hi : lo;
     }
     const int k = cnt - 1;
-    const bool inrange = (cnt >= 1) && (cnt <= K);
+    const bool inrange = (cnt >= 1) && (cnt <= kb);
     unsigned qk, qk1;                     // knots k and k + 1 (out of range: the first / last bin, never used)
-    select_pair<K>(cj, min(max(k, 0), K - 1), qk, qk1);
+    select_pair<KM>(cj, min(max(k, 0), kb - 1), qk, qk1);
     const float ck = (float)qk * (1.0f / FIX), ck1 = (float)qk1 * (1.0f / FIX);
     const float kn0 = RQS_BOUND * (2.0f * ck - 1.0f);
     const float kn1 = RQS_BOUND * (2.0f * ck1 - 1.0f);
@@ -382,11 +392,11 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
     // not own (and for the boundary knots); knots k and k + 1 are the adjacent pair at e = k - base + 1
     float r0, r1;
     {
-        float G[KD0 + 4];
-        G[0] = G[1] = G[KD0 + 2] = G[KD0 + 3] = 0.0f;
+        float G[KD0M + 4];
+        G[0] = G[1] = G[KD0M + 2] = G[KD0M + 3] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < KD0; ++j) G[2 + j] = (j < KD1 || j < nown) ? v[K + j] : 0.0f;
-        select_pair<KD0 + 3>(G, min(max(k - base + 1, 0), KD0 + 2), r0, r1);
+        for (int j = 0; j < KD0M; ++j) G[2 + j] = (j < nown) ? v[KM + j] : 0.0f;
+        select_pair<KD0M + 3>(G, min(max(k - base + 1, 0), KD0M + 2), r0, r1);
     }
     {
         float a, b;
@@ -470,7 +480,7 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
         const float kf = (float)k;
         float u_prev = __builtin_amdgcn_fmed3f(kf + 1.0f, 0.0f, 1.0f);                // u_{-1}: k >= 0
 #pragma unroll
-        for (int m = 0; m < K; ++m) {
+        for (int m = 0; m < KM; ++m) {
             const float u = __builtin_amdgcn_fmed3f(kf - (float)m, 0.0f, 1.0f);
             g[m] = pq[m] * fmaf(u, d_lt, fmaf(u_prev, d_eq, t_gt));
             u_prev = u;
@@ -478,15 +488,16 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
         const float gr0 = inrange ? Gd0 * d0 * soft_clip_grad(r0, A1) : 0.0f;
         const float gr1 = inrange ? Gd1 * d1 * soft_clip_grad(r1, A1) : 0.0f;
 #pragma unroll
-        for (int j = 0; j < 32 - K; ++j) {
+        for (int j = 0; j < 32 - KM; ++j) {
             const bool own = j < nown;
             float t = 0.0f;
             t = (own && (k - 1 == base + j)) ? gr0 : t;
             t = (own && (k == base + j)) ? t + gr1 : t;
-            g[K + j] = t;
+            g[KM + j] = t;
         }
     }
 }
+#undef MF_BIN_ON
 
 // A[in rows of tile] fragment of one output block (64 padded rows) of the last linear layer
 __device__ __forceinline__ void block_linear(const float* W, const float* b, const f32x16_t (&in)[2], float (&v)[32],
@@ -510,7 +521,7 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __res
                                                                    float* __restrict__ y,
                                                                    const float* __restrict__ logp_in,
                                                                    float* __restrict__ logp_out, int init_logp,
-                                                                   Sparsity sp) {
+                                                                   Sparsity sp, int bins_rt) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
     stage_image<BLOCK>(lds, image, g.total);
@@ -536,14 +547,12 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __res
             h[1] = t[1];
         }
         float ladj = 0.0f;
-        // waves walk the features in rotated order so that the waves sharing a SIMD are not all in the same
-        // (MFMA-heavy or VALU-heavy) phase at the same time
 #pragma unroll 1
         for (int i = 0; i < d; ++i) {
             float v[32], gdummy[32];
             block_linear(lds + g.offW3 + i * HID * WS, lds + g.offB3 + i * HID, h, v, col, hh, sp.kend3[i]);
             float yi, li, gxd;
-            rqs_apply<K, 0>(v, xp[i], hh, yi, li, 0.0f, 0.0f, gdummy, gxd);
+            rqs_apply<K, 0>(v, xp[i], hh, yi, li, 0.0f, 0.0f, gdummy, gxd, bins_rt);
             ladj += li;
             if (valid && hh == 0) y[p * d + i] = yi;
         }
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_bwd_kernel(const float* __res
                                                                    const float* __restrict__ gy,
                                                                    const float* __restrict__ glogp,
                                                                    float* __restrict__ gx, float* __restrict__ scratch,
-                                                                   Sparsity sp) {
+                                                                   Sparsity sp, int bins_rt) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
     stage_image<BLOCK>(lds, image, g.total);
@@ -627,7 +636,7 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_bwd_kernel(const float* __res
             block_linear(W3, lds + g.offB3 + i * HID, h[L - 1], v, col, hh, sp.kend3[i]);
             const float gyi = valid ? gy[pc * d + i] : 0.0f;
             float yi, li, gxd;
-            rqs_apply<K, 1>(v, xp[i], hh, yi, li, gyi, gl, gv, gxd);
+            rqs_apply<K, 1>(v, xp[i], hh, yi, li, gyi, gl, gv, gxd, bins_rt);
             // direct path dL/dx_i goes into row i of the dL/dx accumulator tile (row = 4*hh + reg for rows < 8)
 #pragma unroll
             for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
@@ -1239,7 +1248,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                                                                         const float* __restrict__ gy,
                                                                         const float* __restrict__ glogp,
                                                                         float* __restrict__ gx, float* __restrict__ gslab,
-                                                                        int accumulate, Sparsity sp) {
+                                                                        int accumulate, Sparsity sp, int bins_rt) {
     MF_DYN_SMEM(float, lds);
     const ImageLayout g = image_layout(d, L, d);
     float* gimage = gslab + (int64_t)blockIdx.x * g.total;     // this workgroup's slab row
@@ -1403,7 +1412,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 gyi = (i == j) ? gyr[j] : gyi;
             }
             float yi, li, gxd;
-            FB_SPLINE(rqs_apply<K, 1>(v, xi, hh, yi, li, gyi, gl, gv, gxd));
+            FB_SPLINE(rqs_apply<K, 1>(v, xi, hh, yi, li, gyi, gl, gv, gxd, bins_rt));
             WS_ACC(c_[2], t0_);
 #pragma unroll
             for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
@@ -1596,12 +1605,12 @@ struct InvOrder {
 #endif
 
 constexpr int INV_BLOCK = 512;
-template <int K, int L>     // K > 0: rational-quadratic spline;  K == 0: affine
+template <int K, int L>     // K > 0 or RQS_ANY: rational-quadratic spline;  K == 0: affine
 __global__ __launch_bounds__(INV_BLOCK) void layer_inv_kernel(const float* __restrict__ image, int d,
                                                               const float* __restrict__ y, int64_t n,
-                                                              float* __restrict__ x, Sparsity sp, InvOrder io) {
+                                                              float* __restrict__ x, Sparsity sp, InvOrder io, int bins_rt) {
     MF_DYN_SMEM(float, lds);
-    const int nblk = (K > 0) ? d : 1;
+    const int nblk = (K != 0) ? d : 1;
     const ImageLayout g = image_layout(d, L, nblk);
     stage_image<INV_BLOCK>(lds, image, g.total);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
@@ -1621,9 +1630,9 @@ __global__ __launch_bounds__(INV_BLOCK) void layer_inv_kernel(const float* __res
         for (int t = 0; t < d; ++t) {
             MF_NO_HOIST();
             const int i = io.feat[t];
-            const int blk = (K > 0) ? i : 0;
+            const int blk = (K != 0) ? i : 0;
             float v[32];
-            const bool pure_bias = (K > 0) && (sp.kend3[i] == 0);
+            const bool pure_bias = (K != 0) && (sp.kend3[i] == 0);
             if (pure_bias) {
 #pragma unroll
                 for (int m = 0; m < 32; ++m) v[m] = lds[g.offB3 + blk * HID + 32 * (m >> 4) + rowmap(m & 15, hh)];
@@ -1644,14 +1653,14 @@ __global__ __launch_bounds__(INV_BLOCK) void layer_inv_kernel(const float* __res
                 }
                 f32x16_t phi[2];
                 linear64(lds + g.offW3 + blk * HID * WS, lds + g.offB3 + blk * HID, h, phi, col, hh, sp.kend3[blk],
-                         (K > 0) ? sp.kend3[blk] : 0);
+                         (K != 0) ? sp.kend3[blk] : 0);
 #pragma unroll
                 for (int m = 0; m < 32; ++m) v[m] = phi[m >> 4][m & 15];
             }
             float xi;
-            if (K > 0) {
+            if (K != 0) {
                 float li, gxd, gdummy[32];
-                rqs_apply<(K > 0 ? K : 8), 2>(v, yp[i], hh, xi, li, 0.0f, 0.0f, gdummy, gxd);
+                rqs_apply<(K != 0 ? K : 8), 2>(v, yp[i], hh, xi, li, 0.0f, 0.0f, gdummy, gxd, bins_rt);
             } else {
                 // slot i of half 0 = shift_i, of half 1 = scale_i (runtime i: select among the 8 candidate slots)
                 float mine = 0.0f;
@@ -2182,10 +2191,23 @@ extern "C" int64_t mf_flow_image_floats(int d, int hidden_layers) { return image
 // this call?  It needs the mask structure (order) for the compact last-layer image, d <= FB_DMAX accumulator blocks and
 // an LDS budget that fits.  Since the deterministic slab flush replaced the contended float atomics the fused kernel also
 // wins at small batches (25 000 particles, C4 step: 1.21 ms against 1.68 ms for the two-kernel path, profiles/r02), so
-// it is the default for every batch size; MENTFLOW_BWD_FUSED=0 forces the two-kernel path (tests), =1 is the default.
+// it is the default for every batch size; MENTFLOW_BWD_FUSED=0 (read once) or mf_flow_set_bwd_variant(0) force the
+// two-kernel path (tests).
+// backward variant: -1 = default (the environment variable MENTFLOW_BWD_FUSED, read ONCE; unset = fused), 0 = two-kernel
+// path, 1 = fused kernel.  mf_flow_set_bwd_variant overrides it (tests switch variants inside one process).
+static int g_bwd_variant = -1;
+static bool bwd_fused_wanted() {
+    static const int env_default = [] { const char* e = getenv("MENTFLOW_BWD_FUSED"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    return (g_bwd_variant < 0 ? env_default : g_bwd_variant) != 0;
+}
+extern "C" int mf_flow_set_bwd_variant(int variant) {
+    if (variant < -1 || variant > 1) return fail("mf_flow_set_bwd_variant: -1 (default), 0 (two-kernel) or 1 (fused)");
+    g_bwd_variant = variant;
+    return 0;
+}
+
 static bool rqs_bwd_fused(int64_t n, int d, int hidden_layers, const int32_t* order, const Sparsity& sp, size_t* smem) {
-    const char* e = getenv("MENTFLOW_BWD_FUSED");
-    if ((e && atoi(e) == 0) || order == nullptr || d > FB_DMAX) return false;
+    if (!bwd_fused_wanted() || order == nullptr || d > FB_DMAX) return false;
     (void)n;
     size_t fl = image_layout(d, hidden_layers, d).offW3;
     for (int i = 0; i < d; ++i) fl += (size_t)WS * (2 * ((sp.kend3[i] + 3) & ~3));
@@ -2204,7 +2226,18 @@ extern "C" int64_t mf_flow_bwd_scratch_floats(int64_t n, int d, int hidden_layer
     return (2 * (int64_t)hidden_layers + d) * npad * 64;
 }
 
-#define MF_RQS_CASES(X) X(20, 3) X(20, 2) X(8, 3) X(8, 2)
+// Built spline instances: bins 20 (the reference's value, experiments/setup.py:119-121) and 8 (zuko's default) at compile
+// time; every other 2 <= bins <= 21 through the run-time instance (RQS_ANY: slots laid out for 21 bins, slower).
+#define MF_RQS_CASES(X) X(20, 3) X(20, 2) X(8, 3) X(8, 2) X(RQS_ANY, 3) X(RQS_ANY, 2)
+static bool rqs_case_matches(int KK, int bins) {
+    return KK == RQS_ANY ? (bins != 20 && bins != 8 && bins >= 2 && bins <= RQS_KMAX) : bins == KK;
+}
+// slot of this lane half's first derivative logit in the packed last-layer block (mentflow_amd/generate/packing.py): the
+// number of bins for the compile-time instances, 21 for the run-time one; -1: no kernel for this number of bins
+extern "C" int mf_flow_rqs_deriv_slot(int bins) {
+    if (bins == 20 || bins == 8) return bins;
+    return (bins >= 2 && bins <= RQS_KMAX) ? RQS_KMAX : -1;
+}
 
 extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
                                       const float* x, int64_t n, float* y, const float* logp_in, float* logp_out,
@@ -2222,18 +2255,18 @@ extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layer
     if (fwd_block == BB) {                                                                                            \
         MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL, BB>), smem);                                                  \
         MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL, BB>), flow_grid(n, BB / 64), BB, smem, stream, image, d, x, n, y,      \
-                  logp_in, logp_out, init_logp, sp);                                                  \
+                  logp_in, logp_out, init_logp, sp, bins);                                            \
         return check_launch("mf_flow_rqs_layer_fwd");                                                                 \
     }
 #define X(KK, LL)                                                                                                     \
-    if (bins == KK && hidden_layers == LL) {                                                                          \
+    if (rqs_case_matches(KK, bins) && hidden_layers == LL) {                                                          \
         ProfScope prof(PK_FLOW_FWD, stream);                                                                          \
         XB(KK, LL, 256) XB(KK, LL, 512) XB(KK, LL, 1024)                                                              \
         return fail("MENTFLOW_FWD_BLOCK must be 256, 512 or 1024");                                                   \
     }
     MF_RQS_CASES(X)
 #undef X
-    return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: bins in {8,20}, hidden_layers in {2,3})", bins,
+    return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: 2 <= bins <= 21, hidden_layers in {2,3})", bins,
                 hidden_layers);
 }
 
@@ -2280,17 +2313,17 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
             {
                 const int gf = fused_grid(n);
 #define XF(KK, LL)                                                                                                    \
-    if (!launched && bins == KK && hidden_layers == LL) {                                                             \
+    if (!launched && rqs_case_matches(KK, bins) && hidden_layers == LL) {                                             \
         ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
         MF_ALLOW_DYN_SMEM((rqs_layer_bwd_fused_kernel<KK, LL>), smem_f);                                              \
         MF_LAUNCH((rqs_layer_bwd_fused_kernel<KK, LL>), gf, FB_BLOCK, smem_f, stream, image, d, x, n, gy, glogp, gx,   \
-                  gslab, accumulate, sp);                                                                                \
+                  gslab, accumulate, sp, bins);                                                                          \
         launched = true;                                                                                              \
     }
                 MF_RQS_CASES(XF)
 #undef XF
                 if (launched) return check_launch("mf_flow_rqs_layer_bwd(fused)");
-                return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: bins in {8,20}, hidden_layers in {2,3})",
+                return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: 2 <= bins <= 21, hidden_layers in {2,3})",
                             bins, hidden_layers);
             }
         }
@@ -2300,23 +2333,23 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
     // small batches: one tile per SIMD on as many CUs as possible
     const int bwd_block = bwd_block_env == 256 || bwd_block_env == 512 ? bwd_block_env : (ntb <= 4 * NUM_CU ? 256 : 512);
 #define X(KK, LL)                                                                                                     \
-    if (!launched && bins == KK && hidden_layers == LL) {                                                             \
+    if (!launched && rqs_case_matches(KK, bins) && hidden_layers == LL) {                                             \
         ProfScope prof(PK_FLOW_BWD, stream);                                                                          \
         if (bwd_block == 256) {                                                                                       \
             MF_ALLOW_DYN_SMEM((rqs_layer_bwd_kernel<KK, LL, 256>), smem);                                             \
             MF_LAUNCH((rqs_layer_bwd_kernel<KK, LL, 256>), flow_grid(n, 4), 256, smem, stream, image, d, x, n, gy,     \
-                      glogp, gx, scratch, sp);                                                        \
+                      glogp, gx, scratch, sp, bins);                                                  \
         } else {                                                                                                      \
             MF_ALLOW_DYN_SMEM((rqs_layer_bwd_kernel<KK, LL, 512>), smem);                                             \
             MF_LAUNCH((rqs_layer_bwd_kernel<KK, LL, 512>), flow_grid(n, 8), 512, smem, stream, image, d, x, n, gy,     \
-                      glogp, gx, scratch, sp);                                                        \
+                      glogp, gx, scratch, sp, bins);                                                  \
         }                                                                                                             \
         launched = true;                                                                                              \
     }
     MF_RQS_CASES(X)
 #undef X
     if (!launched)
-        return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: bins in {8,20}, hidden_layers in {2,3})",
+        return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: 2 <= bins <= 21, hidden_layers in {2,3})",
                     bins, hidden_layers);
     if (check_launch("mf_flow_rqs_layer_bwd")) return 1;
     const int nwaves = d > hidden_layers ? d : hidden_layers;
@@ -2334,8 +2367,7 @@ extern "C" int64_t mf_flow_affine_image_floats(int d, int hidden_layers) { retur
 // batch size, MENTFLOW_BWD_FUSED=0 forces the two-kernel path
 static bool affine_bwd_fused(int64_t n) {
     (void)n;
-    const char* e = getenv("MENTFLOW_BWD_FUSED");
-    return !(e && atoi(e) == 0);
+    return bwd_fused_wanted();
 }
 
 extern "C" int64_t mf_flow_affine_bwd_scratch_floats(int64_t n, int hidden_layers) {
@@ -2476,15 +2508,15 @@ extern "C" int mf_flow_rqs_layer_inv(const float* image, int d, int hidden_layer
     const Sparsity sp = make_sparsity(d, order, d);
     const size_t smem = sizeof(float) * ((size_t)image_layout(d, hidden_layers, d).total + (INV_BLOCK / 64) * 32 * 8);
 #define X(KK, LL)                                                                                                     \
-    if (bins == KK && hidden_layers == LL) {                                                                          \
+    if (rqs_case_matches(KK, bins) && hidden_layers == LL) {                                                          \
         MF_ALLOW_DYN_SMEM((layer_inv_kernel<KK, LL>), smem);                                                          \
         MF_LAUNCH((layer_inv_kernel<KK, LL>), flow_grid(n, INV_BLOCK / 64), INV_BLOCK, smem, stream, image, d, y, n, x,  \
-                  sp, io);                                                                                            \
+                  sp, io, bins);                                                                                            \
         return check_launch("mf_flow_rqs_layer_inv");                                                                 \
     }
     MF_RQS_CASES(X)
 #undef X
-    return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: bins in {8,20}, hidden_layers in {2,3})", bins,
+    return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: 2 <= bins <= 21, hidden_layers in {2,3})", bins,
                 hidden_layers);
 }
 
@@ -2500,7 +2532,7 @@ extern "C" int mf_flow_affine_layer_inv(const float* image, int d, int hidden_la
     if (hidden_layers == LL) {                                                                                        \
         MF_ALLOW_DYN_SMEM((layer_inv_kernel<0, LL>), smem);                                                           \
         MF_LAUNCH((layer_inv_kernel<0, LL>), flow_grid(n, INV_BLOCK / 64), INV_BLOCK, smem, stream, image, d, y, n, x, sp, \
-                  io);                                                                                                \
+                  io, 0);                                                                                                \
         return check_launch("mf_flow_affine_layer_inv");                                                              \
     }
     MF_AFFINE_CASES(X)

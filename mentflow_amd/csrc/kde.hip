@@ -18,10 +18,11 @@
 // enters the KL discrepancy, keep their relative accuracy); a workgroup (<= 8192 particles: 2^13 * 2^50 < 2^64) flushes
 // every non-zero bin with ONE 64-bit INTEGER global atomic (2^(shift-50) units, exact up to 8192 particles per call,
 // see fix_flush), and a finishing kernel scales and rounds to fp32 once.  Integer sums do not depend on their order: the histograms are bitwise reproducible.
-// Measured on MI355X (tools/ubench_lds_atomics*.hip): ds_add_f32 sustains 0.33 lane-ops/clk/CU, ds_add_u64 2.7 with
-// random addresses (bank conflicts between the 16 lanes of a group) — the float LDS atomic is 8x slower.  The image can
-// be REPLICATED (COPIES = 1, 2, 4, 8, 16): copy c = lane & (COPIES - 1) of entry e lives at e * COPIES + c, so the lanes
-// of a 16-lane group are spread over the LDS banks whatever bins they hit (16 copies: conflict-free by construction).
+// Measured on MI355X (tools/ubench_lds_atomics2.hip, profiles/r02_ubench_lds_atomics2.txt): ds_add_f32 sustains 0.33
+// lane-ops/clk/CU, ds_add_u64 3.4-3.9 with enough waves in flight WHATEVER the address pattern (consecutive, random, one hot
+// row, private copies per lane: all within 10 %; 2.6-2.75 with only 4 waves per CU) — the float LDS atomic is 10x slower,
+// and bank conflicts do not matter: the atomic unit is the bottleneck either way, so the image is kept once (an earlier
+// version replicated it per lane group; that bought nothing and was removed), occupancy is what counts.
 #include "common.h"
 
 namespace mf {
@@ -174,7 +175,12 @@ __global__ __launch_bounds__(BLOCK) void proj_kde1d_fwd_kernel(
     const float delta = cl[1] - cl[0];
     const float inv_delta = 1.0f / delta;
     const float s = delta * inv_sigma;
-    const GaussGamma<(RT > 0 ? RT : 2)> gm = gauss_gamma<(RT > 0 ? RT : 2)>(s);
+    // The factorised window (and, in 2-D, the dead corner cells) assumes s = delta / sigma in [2, 2.6]: below 2 the radius-4
+    // window would drop weights above the quantum, far above it rho^j gam_j overflows to inf * 0.  The C ABI takes radius and
+    // sigma independently, so the specialisation is taken only inside that range (wave-uniform test); any other pair runs
+    // the generic loop with the radius given.
+    const bool fact_ok = RT > 0 && s >= 2.0f && s <= 2.6f;
+    const GaussGamma<(RT > 0 ? RT : 2)> gm = gauss_gamma<(RT > 0 ? RT : 2)>(fact_ok ? s : 2.0f);
     const int64_t p_lo = (int64_t)blockIdx.x * per_wg;
     const int64_t p_hi = min(n, p_lo + per_wg);
     for (int64_t p = p_lo + threadIdx.x; p < p_hi; p += BLOCK) {
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(BLOCK) void proj_kde1d_fwd_kernel(
             const float u = project8(xv, vq);
             const int kc = centre_bin(u, c0, inv_delta, B, R);
             u64* row = img + (size_t)q * B;
-            if (RT > 0) {
+            if (fact_ok) {
                 float w[2 * (RT > 0 ? RT : 2) + 1];
                 gauss_window<(RT > 0 ? RT : 2)>(u, cl, kc, B, inv_sigma, s, gm, w);
 #pragma unroll
@@ -330,7 +336,8 @@ __global__ __launch_bounds__(BLOCK) void proj_kde2d_fwd_kernel(
     const float cx0 = cxl[0], dx = cxl[1] - cxl[0], inv_dx = 1.0f / dx, ssx = dx * inv_sx;
     const float cy0 = cyl[0], dy = cyl[1] - cyl[0], inv_dy = 1.0f / dy, ssy = dy * inv_sy;
     constexpr int RW = RT > 0 ? RT : 2;
-    const GaussGamma<RW> gmx = gauss_gamma<RW>(ssx), gmy = gauss_gamma<RW>(ssy);
+    const bool fact_ok = RT > 0 && ssx >= 2.0f && ssx <= 2.6f && ssy >= 2.0f && ssy <= 2.6f;     // see proj_kde1d_fwd_kernel
+    const GaussGamma<RW> gmx = gauss_gamma<RW>(fact_ok ? ssx : 2.0f), gmy = gauss_gamma<RW>(fact_ok ? ssy : 2.0f);
     const int64_t p_lo = (int64_t)blockIdx.x * per_wg;
     const int64_t p_hi = min(n, p_lo + per_wg);
     for (int64_t p = p_lo + threadIdx.x; p < p_hi; p += BLOCK) {
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(BLOCK) void proj_kde2d_fwd_kernel(
             const int ka = centre_bin(u0, cx0, inv_dx, Bx, Rx);
             const int kb = centre_bin(u1, cy0, inv_dy, By, Ry);
             u64* im = img + (size_t)q * BB;
-            if (RT > 0) {
+            if (fact_ok) {
                 float wx[2 * RW + 1], wy[2 * RW + 1];
                 gauss_window<RW>(u0, cxl, ka, Bx, inv_sx, ssx, gmx, wx);
                 gauss_window<RW>(u1, cyl, kb, By, inv_sy, ssy, gmy, wy);
@@ -416,6 +423,9 @@ __global__ __launch_bounds__(BLOCK) void proj_kde2d_bwd_kernel(
     const float cx0 = cxl[0], inv_dx = 1.0f / (cxl[1] - cxl[0]);
     const float cy0 = cyl[0], inv_dy = 1.0f / (cyl[1] - cyl[0]);
     constexpr int RW = RT > 0 ? RT : 1;
+    // the same cells as the forward: the dead-corner skip of the RT = 4 window is only taken where the forward takes it
+    const float ssx = (cxl[1] - cxl[0]) * inv_sx, ssy = (cyl[1] - cyl[0]) * inv_sy;
+    const bool fact_ok = RT > 0 && ssx >= 2.0f && ssx <= 2.6f && ssy >= 2.0f && ssy <= 2.6f;
     const int64_t base = (int64_t)blockIdx.x * BLOCK * NPT + threadIdx.x;
     float xv[NPT][KDE_DMAX], gv[NPT][KDE_DMAX];
 #pragma unroll
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(BLOCK) void proj_kde2d_bwd_kernel(
                 const int kb = centre_bin(u1, cy0, inv_dy, By, Ry);
                 const float* im = img + q * BB;
                 float du0 = 0.0f, du1 = 0.0f;
-                if (RT > 0) {
+                if (fact_ok) {
                     // same cells as the forward (dead corners skipped); out-of-range bins read a clamped bin, masked
                     // residuals from the tables of bin centres, exactly as the reference forms them
                     float wy[2 * RW + 1], dyw[2 * RW + 1];

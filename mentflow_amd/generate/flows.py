@@ -82,7 +82,17 @@ class _Flow(nn.Module):
 
 
 class AutoregressiveFlow(GenerativeModel):
-    """NSF ("rqs") or MAF ("affine") generator with the reference's ``GenerativeModel`` API."""
+    """NSF ("rqs") or MAF ("affine") generator with the reference's ``GenerativeModel`` API.
+
+    Autograd contract.  ``sample_and_log_prob`` / ``forward`` are differentiable in the base draw ``z`` (as zuko's
+    transform is, flows/zuko.py:28-29) and in the parameters.  By default the PARAMETERS are not inputs of the autograd
+    node: the kernels read the flat buffer the parameters are views of, and the backward deposits the flat gradient
+    straight into the parameters' ``.grad`` (one copy instead of 40 accumulation kernels).  Consequences:
+    ``loss.backward()`` + any optimizer work as usual; ``torch.autograd.grad(loss, generator.parameters())`` raises
+    ("not used in the graph"); ``autograd.grad(loss, other_inputs)`` still fills the parameters' ``.grad`` as a side
+    effect; per-parameter gradient hooks do not fire.  Set ``autograd_parameters = True`` to make the parameters ordinary
+    autograd inputs (one ``torch.cat`` per call and one accumulation per parameter: slower at small batches, identical
+    values) when those features are needed.  tests/test_flow_autograd_contract.py pins both behaviours."""
 
     def __init__(self, features: int, hidden_features: Sequence[int] = (64, 64, 64), transforms: int = 5,
                  kind: str = "rqs", bins: int = 20):
@@ -101,6 +111,7 @@ class AutoregressiveFlow(GenerativeModel):
         self._spec: Optional[ops.FlowSpec] = None
         self._spec_device = None
         self.grad_reduce = None          # set by mentflow_amd.dist for data-parallel runs
+        self.autograd_parameters = False # True: parameters are autograd inputs (see the class docstring)
         self._flat = None                # flat parameter / gradient buffers (see _flatten)
         self._gflat = None
         self._gviews = None
@@ -116,17 +127,33 @@ class AutoregressiveFlow(GenerativeModel):
 
     # ------------------------------------------------------------------ flat parameter / gradient storage
     def _flat_ok(self) -> bool:
-        ps = getattr(self, "_flat_params", None)
-        if not ps or self._flat is None:
-            return False
+        """True iff EVERY current parameter is still the view of the flat buffer that _flatten made: same Parameter
+        objects in the same order, same storage offsets, float32, same device.  (~40 host compares per call.  Checking
+        only the first and last parameter missed ``ps[3].data = ...`` or a swapped Parameter in the middle: the kernels
+        then kept consuming the stale flat slice while parameters() / state_dict() / the optimizer saw the new tensor.)"""
+        ps = self._flat_params
         f = self._flat
-        return (ps[0].device == f.device and ps[0].data_ptr() == f.data_ptr()
-                and ps[-1].data_ptr() == f.data_ptr() + 4 * (f.numel() - ps[-1].numel()))
+        if not ps or f is None:
+            return False
+        cur = list(self.parameters())
+        if len(cur) != len(ps):
+            return False
+        base, off = f.data_ptr(), 0
+        for p, q in zip(cur, ps):
+            if p is not q or p.dtype != torch.float32 or p.device != f.device or p.data_ptr() != base + 4 * off:
+                return False
+            off += p.numel()
+        return off == f.numel()
 
     def _flatten(self) -> None:
         """(Re)build the flat buffers and point every parameter's storage at its slice.  Needed once, and again after
         anything that replaces the parameters' storage (``.to(device)``, ``.float()``)."""
         params = list(self.parameters())
+        bad = [n for n, p in self.named_parameters() if p.dtype != torch.float32]
+        if bad:
+            raise TypeError(f"the gfx950 flow kernels compute in float32; parameter(s) {bad[:3]} are "
+                            f"{next(p.dtype for p in params if p.dtype != torch.float32)} (e.g. after .double() / .half()): "
+                            "convert the generator back with .float()")
         dev = params[0].device
         total = sum(p.numel() for p in params)
         flat = torch.empty(total, dtype=torch.float32, device=dev)
@@ -157,6 +184,8 @@ class AutoregressiveFlow(GenerativeModel):
         if self.grad_reduce is not None:
             self.grad_reduce(gflat)
         params, views = self._flat_params, self._gviews
+        if not any(p.requires_grad for p in params):
+            return                                  # generator frozen as a whole (the call was for dL/dz only)
         if not all(p.requires_grad for p in params):
             raise NotImplementedError("freezing individual flow parameters is not supported (freeze the generator as a whole)")
         if all(p.grad is None for p in params):
@@ -182,11 +211,16 @@ class AutoregressiveFlow(GenerativeModel):
             off += p.numel()
         numel = off
         per_layer = 2 * (L + 1)
+        deriv_slot = None
+        if self.kind == "rqs":
+            deriv_slot = get_lib().mf_flow_rqs_deriv_slot(self.bins)
+            if deriv_slot < 0:
+                raise NotImplementedError(f"bins={self.bins}: the spline kernels take 2 <= bins <= 21 (32 slots per lane half)")
         idx = []
         for t, layer in enumerate(self.layers):
             masks = [lin.mask.cpu() for lin in layer.linears()]
             idx.append(packing.layer_image_index(d, L, self.kind, self.bins, masks,
-                                                 offsets[t * per_layer:(t + 1) * per_layer]))
+                                                 offsets[t * per_layer:(t + 1) * per_layer], deriv_slot))
         image_index = np.concatenate(idx)
         return image_index, packing.invert_index(image_index, numel), idx[0].size
 
@@ -218,8 +252,12 @@ class AutoregressiveFlow(GenerativeModel):
         """x = F(z), log_prob = logN(z) - ladj.  ``z`` may be injected (parity tests); default: fresh base draw."""
         if z is None:
             z = self.inject_z if self.inject_z is not None else self.sample_base(n)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self.parameters())):
             flat = self.flat_parameters()
+            if self.autograd_parameters:
+                # parameters as autograd inputs: the gradient comes back through torch.cat (per-parameter accumulation)
+                flat_ag = torch.cat([p.reshape(-1) for p in self.parameters()])
+                return ops.FlowSampleFn.apply(z, flat_ag, self.spec(), self.grad_reduce, None, None)
             if self._trigger[0].device != flat.device:
                 self._trigger[0] = torch.zeros((), device=flat.device, requires_grad=True)
             return ops.FlowSampleFn.apply(z, flat, self.spec(), None, self._trigger[0], self._deposit_gradient)

@@ -22,8 +22,9 @@ output tile only the k-steps up to its largest class, and the kernels skip the M
 Row permutation of the last layer.  The kernels evaluate the spline of feature i in the two lanes (col, col+32) of
 a particle; a lane half hh holds, in accumulator slot m (0..31), the MFMA row
     rho(hh, m) = 32*(m >> 4) + (m & 3) + 8*((m & 15) >> 2) + 4*hh.
-RQS, K bins, KD0 = K // 2:   half 0: slots 0..K-1 = widths, K..K+KD0-1 = derivatives 0..KD0-1
-                             half 1: slots 0..K-1 = heights, K..      = derivatives KD0..K-2
+RQS, K bins, KD0 = K // 2:   half 0: slots 0..K-1 = widths, DS..DS+KD0-1 = derivatives 0..KD0-1
+                             half 1: slots 0..K-1 = heights, DS..      = derivatives KD0..K-2
+                             DS = K for the compile-time instances (K = 8, 20), 21 for the run-time-bins instance
 affine:                      half 0: slot i = shift_i;  half 1: slot i = scale_i      (single block)
 """
 from __future__ import annotations
@@ -77,21 +78,28 @@ def image_layout(d: int, L: int, nblk: int) -> dict:
     return g
 
 
-def rqs_logical_param(hh: int, m: int, K: int) -> int:
-    """index (0..3K-2) of the spline parameter held in slot m of lane half hh, or -1 if the slot is unused."""
+def rqs_logical_param(hh: int, m: int, K: int, DS: int = None) -> int:
+    """index (0..3K-2) of the spline parameter held in slot m of lane half hh, or -1 if the slot is unused.  DS = slot of
+    the half's first derivative logit: K for the compile-time kernel instances, 21 for the run-time-bins instance
+    (mf_flow_rqs_deriv_slot; slots K..DS-1 are unused there)."""
+    DS = K if DS is None else DS
     KD0 = K // 2
     if m < K:
         return m if hh == 0 else K + m
-    j = m - K
+    if m < DS:
+        return -1
+    j = m - DS
     if hh == 0:
         return 2 * K + j if j < KD0 else -1
     return 2 * K + KD0 + j if j < (K - 1 - KD0) else -1
 
 
-def layer_image_index(d: int, L: int, kind: str, K: int, masks: Sequence[torch.Tensor], offsets: Sequence[int]) -> np.ndarray:
+def layer_image_index(d: int, L: int, kind: str, K: int, masks: Sequence[torch.Tensor], offsets: Sequence[int],
+                      deriv_slot: int = None) -> np.ndarray:
     """int32 [image_floats]: index into the flat parameter vector (or -1).
 
-    masks: bool [out,in] per linear layer (L+1 of them); offsets: flat offset of W_0, b_0, W_1, b_1, ... (2(L+1)).
+    masks: bool [out,in] per linear layer (L+1 of them); offsets: flat offset of W_0, b_0, W_1, b_1, ... (2(L+1));
+    deriv_slot: see rqs_logical_param (default: the compact layout of the compile-time instances).
     """
     total_per_feature = 3 * K - 1 if kind == "rqs" else 2
     nblk = d if kind == "rqs" else 1
@@ -117,7 +125,7 @@ def layer_image_index(d: int, L: int, kind: str, K: int, masks: Sequence[torch.T
         for r in range(HID):
             hh, m = slot_of_row(r)
             if kind == "rqs":
-                t = rqs_logical_param(hh, m, K)
+                t = rqs_logical_param(hh, m, K, deriv_slot)
                 row = blk * total_per_feature + t if t >= 0 else -1
             else:
                 row = (2 * m + hh) if m < d else -1       # feature m: (shift, scale) = rows 2m, 2m+1

@@ -113,7 +113,9 @@ class FlowSampleFn(torch.autograd.Function):
     Two ways to receive the parameter gradient: (a) ``flat`` is an autograd tensor (e.g. ``torch.cat`` of the parameters):
     its gradient is returned to autograd; (b) ``flat`` is a plain buffer, ``trigger`` a leaf that requires grad (so that
     autograd calls this backward) and ``grad_sink(gflat)`` deposits the gradient (AutoregressiveFlow: one flat copy
-    into the parameters' .grad views instead of one accumulation kernel per parameter)."""
+    into the parameters' .grad views instead of one accumulation kernel per parameter).  In form (b) the parameters are
+    NOT part of the autograd graph (see the AutoregressiveFlow docstring for what that implies).  dL/dz is returned when
+    ``z`` requires grad (one more layer-0 input gradient + the base-density term -z dL/dlog_prob)."""
 
     @staticmethod
     def forward(ctx, z: torch.Tensor, flat: torch.Tensor, spec: FlowSpec, grad_reduce=None, trigger=None, grad_sink=None):
@@ -131,7 +133,6 @@ class FlowSampleFn(torch.autograd.Function):
         ctx.grad_reduce = grad_reduce
         ctx.grad_sink = grad_sink
         ctx.save_for_backward(images, *xs[:-1])
-        ctx.mark_non_differentiable()
         return xs[-1], logp
 
     @staticmethod
@@ -152,8 +153,9 @@ class FlowSampleFn(torch.autograd.Function):
         gflat = None
         g = gx
         slabs = {r: torch.empty(spec.T, r, spec.image_floats, dtype=_F32, device=dev) for r in groups}
+        need_gz = ctx.needs_input_grad[0]             # dL/dz: the reference's transform is differentiable in the base draw
         for t in reversed(range(spec.T)):
-            gprev = torch.empty_like(g) if t > 0 else None
+            gprev = torch.empty_like(g) if (t > 0 or need_gz) else None
             for r, members in groups.items():
                 for k, (a, b) in enumerate(members):
                     _layer_bwd(spec, t, images[t], xs[t][a:b], g[a:b], glogp[a:b], None if gprev is None else gprev[a:b],
@@ -164,12 +166,14 @@ class FlowSampleFn(torch.autograd.Function):
             call("mf_flow_grad_reduce", ptr(slab), spec.T, r, spec.image_floats, ptr(spec.grad_index), ptr(part),
                  part.numel(), stream_ptr(part))
             gflat = part if gflat is None else gflat + part
+        # g is now dL/dz through x and the log-det; log_prob also holds the base density logN(z) = -|z|^2/2 - const
+        gz = g - xs[0] * glogp[:, None] if need_gz else None
         if ctx.grad_reduce is not None:
             ctx.grad_reduce(gflat)
         if ctx.grad_sink is not None:
             ctx.grad_sink(gflat)
-            return None, None, None, None, None, None
-        return None, gflat, None, None, None, None
+            return gz, None, None, None, None, None
+        return gz, gflat, None, None, None, None
 
 
 def flow_layers_forward(z: torch.Tensor, flat: torch.Tensor, spec: FlowSpec) -> Tuple[List[torch.Tensor], torch.Tensor]:

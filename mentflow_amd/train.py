@@ -55,13 +55,22 @@ class Trainer:
             gstep = None
             if self.graphed:
                 from .graph import GraphedTrainStep
+                # the learning rate lives in a DEVICE tensor per parameter group (capturable optimizers read it inside
+                # the graph), so a scheduler that moves the rate needs no re-capture: the new value is written into the
+                # same tensor.  Schedulers assign a python float to group["lr"]; it is moved back into the tensor below.
+                dev = next(model.parameters()).device
+                lr_dev = []
+                for g in self.optimizer.param_groups:
+                    t = g["lr"] if torch.is_tensor(g["lr"]) else torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev)
+                    g["lr"] = t
+                    lr_dev.append(t)
                 gstep = GraphedTrainStep(model, self.optimizer, batch_size, guard=True)
-                lr_captured = [g["lr"] for g in self.optimizer.param_groups]
             for iteration in range(iterations):
                 if gstep is not None:
-                    if [g["lr"] for g in self.optimizer.param_groups] != lr_captured:      # the scheduler moved the rate
-                        gstep.recapture()
-                        lr_captured = [g["lr"] for g in self.optimizer.param_groups]
+                    for g, t in zip(self.optimizer.param_groups, lr_dev):
+                        if g["lr"] is not t:                                               # the scheduler moved the rate
+                            t.fill_(float(g["lr"]))
+                            g["lr"] = t
                     gstep.step()
                     L_val, H_val, D_val = (float(v) for v in gstep.scalars().cpu())         # one sync
                     if L_val != L_val or L_val in (float("inf"), float("-inf")):            # train.py:167
@@ -76,7 +85,7 @@ class Trainer:
                         loss.backward()
                         self.optimizer.step()
                 self._log(dict(epoch=epoch, iteration=iteration, L=L_val, H=H_val, D_norm=D_val, batch_size=batch_size,
-                               learning_rate=self.optimizer.param_groups[0]["lr"], penalty=model.penalty_parameter,
+                               learning_rate=float(self.optimizer.param_groups[0]["lr"]), penalty=model.penalty_parameter,
                                time=time.time() - start_time))
                 if L_val < best_loss:                                                             # train.py:197-199
                     best_loss = L_val

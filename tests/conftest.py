@@ -64,3 +64,22 @@ def backend(request):
         assert torch.cuda.is_available(), "gpu-marked test needs a GPU"
         _lib.use_library(_lib.DEFAULT_PATH)
         yield torch.device("cuda", 0)
+
+
+def set_bwd_variant(monkeypatch, value):
+    """Select the flow backward variant for the rest of the test: "1" / True = fused kernel, "0" / False = two-kernel path,
+    None = default.  (The library reads MENTFLOW_BWD_FUSED once; tests switch through the C ABI's mf_flow_set_bwd_variant.)"""
+    from mentflow_amd import _lib
+    v = None if value is None else (str(value) not in ("0", "False"))
+    _lib.set_flow_bwd_variant(v)
+
+
+@pytest.fixture(autouse=True)
+def _reset_bwd_variant():
+    yield
+    from mentflow_amd import _lib
+    if _lib._lib is not None:
+        try:
+            _lib.set_flow_bwd_variant(None)
+        except Exception:
+            pass

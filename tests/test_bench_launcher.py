@@ -44,6 +44,59 @@ def test_self_launch_two_gloo_ranks_on_the_emulator(emu_library):
     assert "EMULATED" in j["data"]                      # a test run can never pass for a measurement
 
 
+def test_two_gloo_ranks_c5_and_strong_scaling_on_the_emulator(emu_library):
+    """(i) workload c5 over 2 ranks: the forward all-reduce carries 100 x 85 x 85 histogram sums (2.9 MB) + the entropy sums;
+    (ii) --scaling strong: a fixed global batch divided over the ranks.  Both lines carry every rank's own clock."""
+    r = _run(["--gpus", "2", "--workload", "c5", "--per-gpu", "64", "--steps", "1", "--warmup", "0", "--repeats", "1",
+              "--no-cpu-baseline", "--meas-samples", "1000", "--test-emulator-lib", emu_library], timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["config"]["global_batch"] == 128
+    assert "c5" in j["config"]["workload"] and j["value"] > 0 and j["config"]["final_loss"] == j["config"]["final_loss"]
+    pr = j["per_rank_ms_per_step"]
+    assert len(pr["ranks"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - j["ms_per_step"]) < 1e-6
+    r = _run(["--gpus", "2", "--workload", "c4", "--scaling", "strong", "--global-batch", "256", "--steps", "1", "--warmup", "0",
+              "--repeats", "1", "--no-cpu-baseline", "--meas-samples", "2000", "--test-emulator-lib", emu_library])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["scaling"] == "strong" and j["config"]["global_batch"] == 256 and j["config"]["per_gpu_batch"] == 128
+    assert abs(j["value"] - 256 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+
+
+def test_sigterm_to_the_launcher_stops_its_ranks(emu_library):
+    """A driver timeout (SIGTERM to the launcher) must not leave rank processes behind holding their GPUs."""
+    import re
+    import signal
+    import time
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--per-gpu", "4096", "--steps", "50", "--warmup", "0",
+                          "--repeats", "5", "--no-cpu-baseline", "--meas-samples", "2000", "--test-emulator-lib", emu_library],
+                         env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    pids, buf = None, ""
+    t0 = time.time()
+    while pids is None and time.time() - t0 < 120:
+        line = p.stderr.readline()
+        buf += line
+        m = re.search(r"pids \[(\d+), (\d+)\]", line)
+        if m:
+            pids = [int(m.group(1)), int(m.group(2))]
+    assert pids, buf
+    time.sleep(3.0)                                     # let the ranks get going
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=60)
+    assert rc != 0
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive, f"rank process {pid} survived the launcher"
+
+
 def test_strong_scaling_splits_the_global_batch():
     import bench
     a = bench.parse_args(["--gpus", "8", "--scaling", "strong"])

@@ -12,6 +12,8 @@ against a common, more accurate value."""
 import pytest
 import torch
 
+from conftest import set_bwd_variant
+
 import mentflow_amd as mf
 from oracle import flow as of
 from oracle.harness import flow_spec_from_generator, oracle_step
@@ -60,7 +62,7 @@ def test_nsf_backward_matches_oracle(backend, d, variant, monkeypatch):
     """variant "fused": rqs_layer_bwd_fused_kernel (opt-in, parameter gradients inside the backward kernel, operands
     transposed through LDS; d = 7 does not fit its LDS budget and silently takes the two-kernel path);
     n = 300 spans three 4-tile groups with a ragged last tile."""
-    monkeypatch.setenv("MENTFLOW_BWD_FUSED", "1" if variant == "fused" else "0")
+    set_bwd_variant(monkeypatch, "1" if variant == "fused" else "0")
     gen = make_generator(backend, d)
     torch.manual_seed(2)
     n = 70 if variant == "two-kernel" else 300
@@ -91,7 +93,7 @@ def test_nsf_backward_matches_oracle(backend, d, variant, monkeypatch):
 def test_nsf_default_init_tight_gates(backend, d, variant, monkeypatch):
     """SURVEY.md §8(d) gates on default-initialised weights (the timed model): x 1e-5, log_prob 1e-4, parameter
     gradients 5e-4 of the largest entry (~3x the error the bench parity gate reports), both backward variants."""
-    monkeypatch.setenv("MENTFLOW_BWD_FUSED", "1" if variant == "fused" else "0")
+    set_bwd_variant(monkeypatch, "1" if variant == "fused" else "0")
     gen = make_generator(backend, d, transforms=5, steep=False)
     torch.manual_seed(12)
     n = 70 if variant == "two-kernel" else 300
@@ -214,7 +216,7 @@ def test_nn_generator_train_step_matches_oracle(backend):
 def test_maf_affine_forward_backward_match_oracle(backend, d, variant, monkeypatch):
     """BASELINE config C1's "affine coupling" flow: zuko MAF (MonotonicAffineTransform); both backward variants
     (affine_layer_bwd_kernel + outer_accum, and affine_layer_bwd_fused_kernel, the default)."""
-    monkeypatch.setenv("MENTFLOW_BWD_FUSED", "1" if variant == "fused" else "0")
+    set_bwd_variant(monkeypatch, "1" if variant == "fused" else "0")
     gen = make_generator(backend, d, kind="maf", transforms=3)
     assert sum(p.numel() for p in gen.parameters()) == 3 * (64 * d + 64 + 2 * (64 * 64 + 64) + 2 * d * 64 + 2 * d)
     torch.manual_seed(5)

@@ -3,6 +3,8 @@
 import pytest
 import torch
 
+from conftest import set_bwd_variant
+
 import mentflow_amd as mf
 from mentflow_amd import ops
 from mentflow_amd.harness import build_problem
@@ -76,13 +78,13 @@ def test_c3_flow_roundtrip_logprob_and_chunked_backward(dev, monkeypatch):
     w = torch.randn(n, 6, device=dev)
     grads = []
     for fused, chunk in (("1", 1 << 19), ("0", 1 << 19), ("0", 100_003)):
-        monkeypatch.setenv("MENTFLOW_BWD_FUSED", fused)
+        set_bwd_variant(monkeypatch, fused)
         gen.spec().bwd_chunk = chunk
         gen.zero_grad()
         xx, ll = gen.sample_and_log_prob(n, z=z)
         ((xx * w).sum() / n + ll.mean()).backward()
         grads.append(torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).clone())
-    monkeypatch.delenv("MENTFLOW_BWD_FUSED")
+    set_bwd_variant(monkeypatch, None)
     gen.spec().bwd_chunk = 1 << 19
     for other in grads[1:]:
         torch.testing.assert_close(grads[0], other, rtol=2e-4, atol=2e-5 * float(grads[0].abs().max()))
@@ -147,13 +149,13 @@ def test_c2_full_size_flow_and_histograms(dev, monkeypatch):
     # the whole loss: fused vs two-kernel backward, and bitwise run-to-run reproducibility of the parameter gradients
     grads = []
     for fused in ("1", "1", "0"):
-        monkeypatch.setenv("MENTFLOW_BWD_FUSED", fused)
+        set_bwd_variant(monkeypatch, fused)
         gen.inject_z = z
         prob.model.zero_grad()
         L, H, D = prob.model.loss(n)
         L.backward()
         grads.append(torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).clone())
-    monkeypatch.delenv("MENTFLOW_BWD_FUSED")
+    set_bwd_variant(monkeypatch, None)
     assert torch.equal(grads[0], grads[1]), "parameter gradients are not bitwise reproducible"
     torch.testing.assert_close(grads[0], grads[2], rtol=2e-4, atol=2e-5 * float(grads[0].abs().max()))
 
@@ -214,14 +216,14 @@ def test_c5_full_size_step_is_reproducible_and_variant_independent(dev, monkeypa
     z = torch.randn(n, 6, device=dev)
     runs = []
     for fused in ("1", "1", "0"):
-        monkeypatch.setenv("MENTFLOW_BWD_FUSED", fused)
+        set_bwd_variant(monkeypatch, fused)
         gen.inject_z = z
         prob.model.zero_grad()
         L, H, D = prob.model.loss(n)
         L.backward()
         runs.append((L.detach().clone(), H.detach().clone(), torch.stack(D).detach().clone(),
                      torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).clone()))
-    monkeypatch.delenv("MENTFLOW_BWD_FUSED")
+    set_bwd_variant(monkeypatch, None)
     for a, b in zip(runs[0], runs[1]):
         assert torch.equal(a, b), "C5 step is not bitwise reproducible"
     assert torch.equal(runs[0][0], runs[2][0]) and torch.equal(runs[0][2], runs[2][2])      # forward is the same code

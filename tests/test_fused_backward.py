@@ -6,6 +6,8 @@ see — the inline-asm scheduling (LDS prefetch distances, MFMA -> VALU read pad
 import pytest
 import torch
 
+from conftest import set_bwd_variant
+
 import mentflow_amd as mf
 
 
@@ -18,7 +20,7 @@ def test_fused_backward_equals_two_kernel_backward(d, bins, n, monkeypatch):
     dev = torch.device("cuda", 0)
     res = []
     for fused in ("1", "0"):
-        monkeypatch.setenv("MENTFLOW_BWD_FUSED", fused)
+        set_bwd_variant(monkeypatch, fused)
         torch.manual_seed(0)
         gen = mf.generate.build_generator("nsf", device=dev, input_features=d, output_features=d, hidden_layers=3,
                                           hidden_units=64, transforms=3, bins=bins)

@@ -1,7 +1,6 @@
 """Development tool: builds a -DMF_WS_DIAG copy of the library, runs the fused backward and prints where wave 0 of
-every workgroup spends its time (s_memtime stamps, 100 MHz)."""
+every workgroup spends its time (s_memtime stamps: shader cycles; the stamps themselves cost ~3 %)."""
 import ctypes, os, subprocess, sys
-os.environ["MENTFLOW_BWD_FUSED"] = "1"
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -33,7 +32,7 @@ a = aw[:, 0, :]
 groups = (n // 32) / 4 / 256
 names = ["trunk fwd", "phi = W3 h (x d)", "rqs_apply (x d)", "barrier A (x d)", "stage gv (x d)", "barrier B (x d)",
          "dW last layer (x d)", "final flush (x groups!)", "gh += W3^T gv (x d)", "trunk bwd + dW", "gx", "TOTAL", " trunk: stage+barriers", " trunk: dW (x2)", " trunk: W^T chains (x2)", " level 0: stage + dW"]
-print("groups per workgroup:", groups, " (ticks of s_memtime, 100 MHz: x21 for 2.1 GHz cycles)")
+print("groups per workgroup:", groups, " (ticks of s_memtime = shader cycles)")
 for q, nm in enumerate(names):
     print(f"  {nm:24s} {a[:, q].mean() / groups:9.1f} ticks per group   {100 * a[:, q].mean() / a[:, 11].mean():5.1f} %")
 
