@@ -22,7 +22,12 @@ import torch
 class Trainer:
     def __init__(self, model, optimizer, lr_scheduler=None, plot: Optional[Callable] = None, eval: Optional[Callable] = None,
                  output_dir: Optional[str] = None, notebook: bool = False, load_best: bool = True, verbose: bool = True,
-                 graphed: bool = False) -> None:
+                 graphed: bool = False, lr_on_device: bool = False) -> None:
+        """graphed: replay every epoch's steps from a hipGraph.  A float learning rate is baked into the graph: when a
+        scheduler moves it the epoch's graph is re-captured (3 eager warm-up steps + capture) — bit-identical to the eager
+        Trainer.  lr_on_device=True keeps the rate in a device tensor per parameter group instead (no re-capture at all:
+        for schedulers that move the rate often); torch's AdamW then multiplies by an fp32 tensor where it folds a python
+        float otherwise, so results differ from the float-rate run in the last bits."""
         self.model = model
         self.optimizer = optimizer
         self.lr_scheduler = lr_scheduler
@@ -32,6 +37,7 @@ class Trainer:
         self.load_best = load_best
         self.verbose = verbose
         self.graphed = graphed
+        self.lr_on_device = lr_on_device
         self.history: Dict[str, List] = {}
 
     def _log(self, info: dict) -> None:
@@ -55,22 +61,30 @@ class Trainer:
             gstep = None
             if self.graphed:
                 from .graph import GraphedTrainStep
-                # the learning rate lives in a DEVICE tensor per parameter group (capturable optimizers read it inside
-                # the graph), so a scheduler that moves the rate needs no re-capture: the new value is written into the
-                # same tensor.  Schedulers assign a python float to group["lr"]; it is moved back into the tensor below.
-                dev = next(model.parameters()).device
-                lr_dev = []
-                for g in self.optimizer.param_groups:
-                    t = g["lr"] if torch.is_tensor(g["lr"]) else torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev)
-                    g["lr"] = t
-                    lr_dev.append(t)
+                gstep = None
+                lr_dev = None
+                if self.lr_on_device:
+                    # the learning rate lives in a DEVICE tensor per parameter group (capturable optimizers read it inside
+                    # the graph), so a scheduler that moves the rate needs no re-capture: the new value is written into
+                    # the same tensor.  Schedulers assign a python float to group["lr"]; it is moved back below.
+                    dev = next(model.parameters()).device
+                    lr_dev = []
+                    for g in self.optimizer.param_groups:
+                        t = g["lr"] if torch.is_tensor(g["lr"]) else torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev)
+                        g["lr"] = t
+                        lr_dev.append(t)
                 gstep = GraphedTrainStep(model, self.optimizer, batch_size, guard=True)
+                lr_captured = [g["lr"] for g in self.optimizer.param_groups]
             for iteration in range(iterations):
                 if gstep is not None:
-                    for g, t in zip(self.optimizer.param_groups, lr_dev):
-                        if g["lr"] is not t:                                               # the scheduler moved the rate
-                            t.fill_(float(g["lr"]))
-                            g["lr"] = t
+                    if lr_dev is not None:
+                        for g, t in zip(self.optimizer.param_groups, lr_dev):
+                            if g["lr"] is not t:                                           # the scheduler moved the rate
+                                t.fill_(float(g["lr"]))
+                                g["lr"] = t
+                    elif [g["lr"] for g in self.optimizer.param_groups] != lr_captured:    # float rate: baked into the graph
+                        gstep.recapture()
+                        lr_captured = [g["lr"] for g in self.optimizer.param_groups]
                     gstep.step()
                     L_val, H_val, D_val = (float(v) for v in gstep.scalars().cpu())         # one sync
                     if L_val != L_val or L_val in (float("inf"), float("-inf")):            # train.py:167

@@ -110,3 +110,47 @@ def test_graphed_trainer_matches_eager_trainer_and_undo():
     assert any(not torch.equal(a, b) for a, b in zip(before, g._state))
     g.undo_last_step()
     assert all(torch.equal(a, b) for a, b in zip(before, g._state))
+
+
+def test_graphed_trainer_with_the_learning_rate_on_the_device():
+    """Trainer(graphed=True, lr_on_device=True): a scheduler that moves the rate costs no re-capture (the captured AdamW reads
+    the rate from a device tensor that the Trainer refreshes after every scheduler step), while the default float rate
+    re-captures on every change.  The reference's scheduler API: ReduceLROnPlateau.step(loss) (train.py:214)."""
+    from mentflow_amd import _lib
+    from mentflow_amd import graph as mfgraph
+    _lib.use_library(_lib.DEFAULT_PATH)
+    dev = torch.device("cuda", 0)
+    n = 25_000
+    hist, captures = {}, {}
+    real_recapture = mfgraph.GraphedTrainStep.recapture
+    for on_device in (False, True):
+        prob = build_problem(ndim=6, num=25, bins=64, xmax=4.0, seed=2, transforms=5, prior_scale=1.0, device=dev,
+                             dist_name="rings", meas_samples=100_000)
+        model = prob.model
+        torch.manual_seed(0)
+        model.generator.inject_z = torch.randn(n, 6, device=dev)
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.0, capturable=True)
+        # mode="max" on a decreasing loss + patience 0: the rate drops by 0.7 at (almost) every step
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="max", factor=0.7, patience=0, min_lr=1e-5)
+        count = [0]
+
+        def counting(self, _c=count):
+            _c[0] += 1
+            return real_recapture(self)
+
+        mfgraph.GraphedTrainStep.recapture = counting
+        try:
+            tr = mf.train.Trainer(model, opt, sched, verbose=False, graphed=True, lr_on_device=on_device)
+            tr.train(epochs=1, iterations=6, batch_size=n, rtol=-1, atol=-1, dmax=1e-12, penalty_start=10.0, eval_batch_size=n)
+        finally:
+            mfgraph.GraphedTrainStep.recapture = real_recapture
+        hist[on_device], captures[on_device] = tr.history, count[0]
+    lrs = hist[True]["learning_rate"]
+    assert captures[True] == 1, captures                        # the construction-time capture only
+    assert captures[False] >= 4, captures                       # float rate: one re-capture per change
+    assert lrs[0] == pytest.approx(2e-3) and lrs[-1] < 0.5 * lrs[0] and all(a >= b for a, b in zip(lrs, lrs[1:])), lrs
+    assert hist[False]["learning_rate"] == pytest.approx(lrs, rel=1e-6)
+    Ls = hist[True]["L"]
+    assert all(v == v for v in Ls) and Ls[-1] < Ls[0]
+    # same training up to the last bits of AdamW's rate arithmetic (fp32 tensor rate against a folded python float)
+    assert hist[False]["L"] == pytest.approx(Ls, rel=1e-4)

@@ -26,6 +26,6 @@ echo "c5 sq done"
 cd $GRAFT_REPO_ROOT && python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python3 bench.py --scaling strong --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_strong_n1.json 2> $OUT/bench_strong_n1.err
 python3 bench.py --workload c5 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c5.json 2> $OUT/bench_c5.err
-MENTFLOW_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline > $OUT/bench_2ranks_shared.json 2> $OUT/bench_2ranks_shared.err
+MENTFLOW_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline 2> $OUT/bench_2ranks_shared.err | grep "^{" > $OUT/bench_2ranks_shared.json
 echo "${2:-unknown}" > $OUT/commit.txt
 tail -c 1500 $OUT/bench_default.json
