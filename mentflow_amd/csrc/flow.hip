@@ -807,6 +807,36 @@ __device__ __forceinline__ void chain64(f32x16_t& acc, const float* wl, int g0, 
 #endif
 }
 
+#ifdef MF_ASM_CHAIN
+__device__ __forceinline__ void mfma4_half(f32x16_t& acc, const float (&a)[4], float b0, float b1) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %1, %3, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %2, %4, %0"
+        : "+v"(acc)
+        : "v"(a[0]), "v"(a[1]), "v"(b0), "v"(b1));
+}
+#endif
+// acc += A * B over 7 full groups and the first two k-steps of the eighth (30 of 32 k-steps): the last-layer transposed
+// product of a spline with 20 bins, whose slots 30 and 31 are padding in both lane halves
+template <int KS, class BOp>
+__device__ __forceinline__ void chain64_30(f32x16_t& acc, const float* wl, const BOp& b) {
+#ifdef MF_ASM_CHAIN
+    const unsigned addr = lds_addr(wl);
+    float a0[4], a1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a0[j] = wl[kcol(j) * KS];
+#define MF_G(G, CUR, NXT) mfma4_pf<KS, 4 * G + 4, BOp::agpr>(acc, CUR, NXT, addr, b.template get<4 * G>(), b.template get<4 * G + 1>(), \
+                                                             b.template get<4 * G + 2>(), b.template get<4 * G + 3>());
+    MF_G(0, a0, a1) MF_G(1, a1, a0) MF_G(2, a0, a1) MF_G(3, a1, a0) MF_G(4, a0, a1) MF_G(5, a1, a0) MF_G(6, a0, a1)
+#undef MF_G
+    mfma4_half(acc, a1, b.template get<28>(), b.template get<29>());
+    mfma_drain(acc);
+#else
+    chain64<KS>(acc, wl, 0, 8, b);
+#endif
+}
+
 // Two chains over the SAME B operand back to back (the two 32-row tiles of one product): acc0 += A0 * B over the k-step
 // groups [S0, E0), acc1 += A1 * B over [S1, E1) (mask-bounded ranges: the skipped groups only multiply zeros).  The last
 // group of the first chain requests the first fragments of the second (no exposed LDS round trip between them) and only
@@ -910,6 +940,18 @@ __device__ __forceinline__ void chain64x2(f32x16_t& acc0, f32x16_t& acc1, const 
 MF_DEF_MFMA8(v, MF_BC_V)
 MF_DEF_MFMA8(a, MF_BC_A)
 #undef MF_DEF_MFMA8
+// last group of a chain with only TWO k-steps left (the spline uses 30 of a lane half's 32 slots: the k-steps of the two
+// padding slots would multiply zeros)
+__device__ __forceinline__ void mfma8_half(f32x16_t& acc0, f32x16_t& acc1, const float (&a)[8], float b0, float b1) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %1, %4, %6, %1\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %1, %5, %7, %1"
+        : "+v"(acc0), "+v"(acc1)
+        : "v"(a[0]), "v"(a[1]), "v"(a[4]), "v"(a[5]), "v"(b0), "v"(b1));
+}
 template <int KS, int S4N, bool BA = false>
 __device__ __forceinline__ void mfma8_pf(f32x16_t& acc0, f32x16_t& acc1, const float (&a)[8], float (&n)[8], unsigned addr0,
                                          unsigned addr1, float b0, float b1, float b2, float b3) {
@@ -923,7 +965,8 @@ __device__ __forceinline__ void mfma8_last(f32x16_t& acc0, f32x16_t& acc1, const
     else mfma8_last_v(acc0, acc1, a, b0, b1, b2, b3);
 }
 #endif
-template <int KS, int NG, class BOp>
+// TAIL2: the last of the NG groups only has its first two k-steps (k-steps 4 NG - 2, 4 NG - 1 multiply padding)
+template <int KS, int NG, bool TAIL2 = false, class BOp>
 __device__ __forceinline__ void chain64x2i(f32x16_t& acc0, f32x16_t& acc1, const float* wl0, const float* wl1, const BOp& b) {
     static_assert(NG >= 1 && NG <= 8, "1..8 groups");
 #ifdef MF_ASM_CHAIN
@@ -940,6 +983,8 @@ __device__ __forceinline__ void chain64x2i(f32x16_t& acc0, f32x16_t& acc1, const
             mfma8_pf<KS, (4 * G + 4) & 31, BOp::agpr>(acc0, acc1, CUR, NXT, addr0, addr1, b.template get<4 * G>(),   \
                                            b.template get<4 * G + 1>(), b.template get<4 * G + 2>(),                 \
                                            b.template get<4 * G + 3>());                                             \
+        else if constexpr (TAIL2)                                                                                    \
+            mfma8_half(acc0, acc1, CUR, b.template get<4 * G>(), b.template get<4 * G + 1>());                       \
         else                                                                                                         \
             mfma8_last<BOp::agpr>(acc0, acc1, CUR, b.template get<4 * G>(), b.template get<4 * G + 1>(),               \
                                   b.template get<4 * G + 2>(),                                                       \
@@ -1429,9 +1474,11 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 const float* r0 = (col < nc ? W3 + col * WS : zrow) + 4 * hh;
                 if (rt1_i != 0) {                                  // ... and so does hidden tile 1
                     const float* r1 = (32 + col < nc ? W3 + (32 + col) * WS : zrow) + 4 * hh;
-                    chain64x2i<1, 8>(gh[0], gh[1], r0, r1, BVec{gv});
+                    if constexpr (K == 20) chain64x2i<1, 8, true>(gh[0], gh[1], r0, r1, BVec{gv});     // 30 slots used
+                    else chain64x2i<1, 8>(gh[0], gh[1], r0, r1, BVec{gv});
                 } else {
-                    chain64<1>(gh[0], r0, 0, 8, BVec{gv});
+                    if constexpr (K == 20) chain64_30<1>(gh[0], r0, BVec{gv});
+                    else chain64<1>(gh[0], r0, 0, 8, BVec{gv});
                 }
             }
             WS_ACC(c_[8], t0_);
@@ -1454,7 +1501,9 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         // cannot be indexed by i: two features per iteration use accO[0] and accO[1], then the array is rotated by two
         // (register moves; FB_DMAX / 2 iterations bring every block back to its place).  A switch on i whose cases name
         // accO[0..5] removes the 96 moves per pair but costs more than it saves (r03: +290 scalar instructions per group
-        // for the dispatch, 17.46 ms against 17.27 per step); rotating after every feature cost twice the moves.
+        // for the dispatch, 17.46 ms against 17.27 per step); rotating after every feature cost twice the moves; unrolling
+        // the three iterations (no rotation at all, 1.7 MB of code object instead of 0.96) thrashes the instruction cache:
+        // 18.06 ms.
         static_assert(FB_DMAX % 2 == 0, "two features per iteration");
 #pragma unroll 1
         for (int i = 0; i < FB_DMAX; i += 2) {
