@@ -492,46 +492,58 @@ def run_worker(args) -> int:
         }
         kernels = {k: v for k, v in prof.items() if v[1] > 0}
         if kernels:
-            # dominant kernel by summed HIP-event time inside the timed regions
-            dom = max(kernels, key=lambda k: kernels[k][0])
-            dom_ms, dom_cnt = kernels[dom]
-            launches_per_step = dom_cnt / total_steps
-            flow_k = dom in ("flow_layer_fwd", "flow_layer_bwd", "outer_accum")
-            per_launch_particles = per_gpu * (T if flow_k else 1) / launches_per_step
-            avg_s = dom_ms / dom_cnt * 1e-3
             # the fused backward kernel (no outer_accum launches) does backward-data AND the parameter gradients: 2 F_layer
             fused_bwd = "outer_accum" not in kernels
-            alg_flops = {"flow_layer_fwd": lf, "flow_layer_bwd": 2 * lf if fused_bwd else lf, "outer_accum": lf}.get(dom)
-            roof = {"kernel": dom + (" (fused: backward-data + parameter gradients)" if dom == "flow_layer_bwd" and fused_bwd else "")}
-            if alg_flops is not None:
-                roof.update(bound="mfma", unit="TFLOP/s", peak=PEAK_MFMA_F32,
-                            achieved=alg_flops * per_launch_particles / avg_s / 1e12,
-                            algorithmic_per_launch=f"{alg_flops} FLOP/particle x {int(per_launch_particles)} particles")
-            elif dom.endswith("_fwd"):
-                # KDE forward: every particle adds (2R+1) [1-D] or (2R+1)^2 [2-D] fixed-point weights per projection with
-                # 64-bit LDS atomics; the ceiling is the measured ds_add_u64 issue rate of the chip, not HBM
-                visited = P * (9 if dom == "kde1d_fwd" else 69)      # window cells visited (2-D: 81 - 12 dead corners)
-                with torch.no_grad():
-                    xs = model.generator.sample(8192)
-                ops_pp = kde_issued_atomics(prob, xs)                # ... of which these carry a non-zero fixed-point weight
-                peak = LDS_ATOMIC_U64_PER_CLK_CU * NUM_CU * CLOCK_GHZ            # G lane-atomics / s
-                roof.update(bound="lds_atomic", unit="G ds_add_u64/s", peak=peak,
-                            peak_source="builder-measured: tools/ubench_lds_atomics2.hip, profiles/r02_ubench_lds_atomics2.txt "
-                                        "(3.9 ds_add_u64 per clock and CU x 256 CUs x 2.4 GHz); not a guide number",
-                            achieved=ops_pp * per_launch_particles / avg_s / 1e9,
-                            algorithmic_per_launch=f"{ops_pp:.1f} issued LDS atomics/particle (of {visited} window cells visited; "
-                                                   f"counted on 8192 of the model's particles, weights >= 2^-50) x "
-                                                   f"{int(per_launch_particles)} particles",
-                            hbm_GBps=4 * d * per_launch_particles / avg_s / 1e9)
-            else:   # KDE backward: row reads + writes
-                nbytes = 8 * d * per_launch_particles
-                roof.update(bound="hbm", unit="GB/s", peak=PEAK_HBM, achieved=nbytes / avg_s / 1e9,
-                            algorithmic_per_launch=f"{8 * d} B/particle x {int(per_launch_particles)} particles")
-            roof["frac"] = roof["achieved"] / roof["peak"]
-            roof["avg_launch_ms"] = dom_ms / dom_cnt
-            roof["launches"] = dom_cnt
+            issued = {}                                  # KDE forward: issued LDS atomics per particle, counted once
+
+            def kernel_roofline(name):
+                """Roofline entry of one timed kernel: algorithmic work per launch / HIP-event average launch duration."""
+                ms, cnt = kernels[name]
+                flow_k = name in ("flow_layer_fwd", "flow_layer_bwd", "outer_accum")
+                per_launch_particles = per_gpu * (T if flow_k else 1) / (cnt / total_steps)
+                avg_s = ms / cnt * 1e-3
+                alg_flops = {"flow_layer_fwd": lf, "flow_layer_bwd": 2 * lf if fused_bwd else lf, "outer_accum": lf}.get(name)
+                roof = {"kernel": name + (" (fused: backward-data + parameter gradients)" if name == "flow_layer_bwd" and fused_bwd else "")}
+                if alg_flops is not None:
+                    roof.update(bound="mfma", unit="TFLOP/s", peak=PEAK_MFMA_F32,
+                                achieved=alg_flops * per_launch_particles / avg_s / 1e12,
+                                algorithmic_per_launch=f"{alg_flops} FLOP/particle x {int(per_launch_particles)} particles")
+                elif name.endswith("_fwd"):
+                    # KDE forward: every particle adds fixed-point weights to the (2R+1) [1-D] or (2R+1)^2 - 12 [2-D] window
+                    # cells of each projection with 64-bit LDS atomics — those with a non-zero weight; the ceiling is the
+                    # measured ds_add_u64 issue rate of the chip, not HBM
+                    visited = P * (9 if name == "kde1d_fwd" else 69)
+                    if name not in issued:
+                        with torch.no_grad():
+                            issued[name] = kde_issued_atomics(prob, model.generator.sample(8192))
+                    ops_pp = issued[name]
+                    peak = LDS_ATOMIC_U64_PER_CLK_CU * NUM_CU * CLOCK_GHZ            # G lane-atomics / s
+                    roof.update(bound="lds_atomic", unit="G ds_add_u64/s", peak=peak,
+                                peak_source="builder-measured: tools/ubench_lds_atomics2.hip, profiles/r02_ubench_lds_atomics2.txt "
+                                            "(3.9 ds_add_u64 per clock and CU x 256 CUs x 2.4 GHz); not a guide number",
+                                achieved=ops_pp * per_launch_particles / avg_s / 1e9,
+                                algorithmic_per_launch=f"{ops_pp:.1f} issued LDS atomics/particle (of {visited} window cells visited; "
+                                                       f"counted on 8192 of the model's particles, weights >= 2^-50) x "
+                                                       f"{int(per_launch_particles)} particles",
+                                hbm_GBps=4 * d * per_launch_particles / avg_s / 1e9)
+                else:   # KDE backward: row reads + writes
+                    nbytes = 8 * d * per_launch_particles
+                    roof.update(bound="hbm", unit="GB/s", peak=PEAK_HBM, achieved=nbytes / avg_s / 1e9,
+                                algorithmic_per_launch=f"{8 * d} B/particle x {int(per_launch_particles)} particles")
+                roof["frac"] = roof["achieved"] / roof["peak"]
+                roof["avg_launch_ms"] = ms / cnt
+                roof["launches"] = cnt
+                return roof
+
+            # dominant kernel by summed HIP-event time inside the timed regions
+            dom = max(kernels, key=lambda k: kernels[k][0])
+            roof = kernel_roofline(dom)
             roof["traffic"], roof["traffic_source"] = traffic_from_profile(dom, args.workload, per_gpu, fused_bwd)
             out["roofline"] = roof
+            # the same accounting for every timed kernel (the dominant one is `roofline`)
+            out["kernel_rooflines"] = {k: {q: v for q, v in kernel_roofline(k).items()
+                                           if q in ("bound", "unit", "peak", "achieved", "frac", "avg_launch_ms", "algorithmic_per_launch")}
+                                       for k in kernels}
             out["step_mfma_frac"] = 3 * T * lf * (value / world) / (PEAK_MFMA_F32 * 1e12)
             out["kernel_ms_per_step"] = {k: v[0] / total_steps for k, v in kernels.items()}
         log("gpu leg: " + json.dumps({k: out.get(k) for k in ("value", "ms_per_step", "timed_regions", "roofline",

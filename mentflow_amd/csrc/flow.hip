@@ -328,9 +328,16 @@ __device__ __forceinline__ void select_pair(const T (&t)[N + 1], int idx, T& lo,
 // loops over 21 bins mask the unused ones.  Slower (all 21 iterations run), same arithmetic.
 constexpr int RQS_ANY = -1;
 constexpr int RQS_KMAX = 21;
-template <int K, int MODE>
+struct NoSink {
+    __device__ __forceinline__ void operator()(int, float) const {}
+};
+// sink(m, g[m]) is called as soon as slot m of the adjoint is final (MODE 1): the fused backward stores it into the LDS
+// staging tile right there, so that the 8 KB a wave stages per feature trickle through the LDS write path underneath the
+// adjoint's VALU work instead of as one burst in front of the next MFMA chain (whose fragment reads queue behind it)
+template <int K, int MODE, class Sink = NoSink>
 __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh, float& y_out, float& ladj_out,
-                                          float gy, float gl, float (&g)[32], float& gx_out, int kbins = 0) {
+                                          float gy, float gl, float (&g)[32], float& gx_out, int kbins = 0,
+                                          const Sink& sink = Sink()) {
     constexpr int KM = K > 0 ? K : RQS_KMAX;                   // loop / table bound; derivative slots start at KM
     constexpr int KD0M = KM / 2;                               // table bound of the derivatives per half
     const int kb = K > 0 ? K : kbins;                          // bins
@@ -483,6 +490,7 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
         for (int m = 0; m < KM; ++m) {
             const float u = __builtin_amdgcn_fmed3f(kf - (float)m, 0.0f, 1.0f);
             g[m] = pq[m] * fmaf(u, d_lt, fmaf(u_prev, d_eq, t_gt));
+            sink(m, g[m]);
             u_prev = u;
         }
         const float gr0 = inrange ? Gd0 * d0 * soft_clip_grad(r0, A1) : 0.0f;
@@ -494,6 +502,7 @@ __device__ __forceinline__ void rqs_apply(const float (&v)[32], float x, int hh,
             t = (own && (k - 1 == base + j)) ? gr0 : t;
             t = (own && (k == base + j)) ? t + gr1 : t;
             g[KM + j] = t;
+            sink(KM + j, t);
         }
     }
 }
@@ -1129,6 +1138,28 @@ __device__ __forceinline__ void stage_x_rows(float* S, int col, int hh, int d, c
             if (j < d) S[(j & 3) * FB_PS + 32 * (j >> 2) + col] = xr[j];
     }
 }
+// ReLU / ReLU-mask fused with the staging store of the same register: the stores are issued between the VALU instructions
+// instead of as a burst of 8 KB per wave (x 4 waves through a 64-85 B/clk write path) in front of the next LDS reader
+__device__ __forceinline__ void relu2_stage(f32x16_t (&h)[2], float* S, int lane) {
+    float* q = S + lane;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            h[rt][r] = fmaxf(h[rt][r], 0.0f);
+            q[(16 * rt + r) * FB_PS] = h[rt][r];
+        }
+}
+__device__ __forceinline__ void relu_mask_stage(f32x16_t (&gh)[2], const f32x16_t (&h)[2], float* S, int lane) {
+    float* q = S + lane;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            gh[rt][r] = (h[rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
+            q[(16 * rt + r) * FB_PS] = gh[rt][r];
+        }
+}
 // float offset of (row i of row tile ra, particle 16 kk) within a staged tile
 __device__ __forceinline__ int stage_row_offset(int ra, int i, int kk) {
     return (16 * ra + (i & 3) + 4 * (i >> 3)) * FB_PS + 32 * ((i >> 2) & 1) + 16 * kk;
@@ -1407,13 +1438,27 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                         default: chain64x2i<1, 8>(h[l][0], h[l][1], w0, w1, bt); break;       // equal ranges: interleaved
                     }
                 }
+#ifdef MF_FB_STAGE_BURST
                 relu2(h[l]);
+#else
+                if (l == L - 1) {
+                    FB_SYNC();                           // the previous group's last product has read S_A / S_B
+                    relu2_stage(h[l], myB, lane);
+                } else {
+                    relu2(h[l]);
+                }
+#endif
             }
             if (L == 1) { h[0][0] = h0[0]; h[0][1] = h0[1]; }
         }
         WS_ACC(c_[0], t0_);
-        FB_SYNC();                                   // the previous group's last product has read S_A / S_B
-        stage_tile(myB, lane, h[L - 1]);
+#ifndef MF_FB_STAGE_BURST
+        if (L == 1)
+#endif
+        {
+            FB_SYNC();                                   // the previous group's last product has read S_A / S_B
+            stage_tile(myB, lane, h[L - 1]);
+        }
         // ---- output blocks: spline forward + adjoint, dL/dh_last, last-layer weight gradients
         f32x16_t gh[2];
         f32x16_t gacc;
@@ -1457,15 +1502,34 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 gyi = (i == j) ? gyr[j] : gyi;
             }
             float yi, li, gxd;
+#ifndef MF_FB_LATE_BARRIER_A
+            // barrier A ("product i-1 has read S_A") sits AHEAD of the spline: every wave passed product i-1 a whole phi
+            // chain ago, and with nothing between the adjoint and the staging stores the compiler is free to issue each
+            // ds_write as its value is ready — the 32 KB of a staging event then drain through the 64 B/clk LDS write
+            // path underneath the adjoint's VALU work instead of in one burst that all four waves sit through
+            if (i > 0) FB_SYNC();
+#endif
+#if defined(MF_FB_STAGE_BURST) || defined(MF_FB_NO_SPLINE) || defined(MF_FB_LATE_BARRIER_A)
             FB_SPLINE(rqs_apply<K, 1>(v, xi, hh, yi, li, gyi, gl, gv, gxd, bins_rt));
+#else
+            {
+                float* const qA = myA + lane;
+                auto to_stage = [qA](int m, float val) { qA[m * FB_PS] = val; };
+                rqs_apply<K, 1>(v, xi, hh, yi, li, gyi, gl, gv, gxd, bins_rt, to_stage);     // its two loops cover all 32 slots
+            }
+#endif
             WS_ACC(c_[2], t0_);
 #pragma unroll
             for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
             t0_ = WS_T();
+#ifdef MF_FB_LATE_BARRIER_A
             if (i > 0) FB_SYNC();                    // product i-1 has read S_A
+#endif
             WS_ACC(c_[3], t0_);
             t0_ = WS_T();
+#if defined(MF_FB_STAGE_BURST) || defined(MF_FB_NO_SPLINE) || defined(MF_FB_LATE_BARRIER_A)
             stage_tile(myA, lane, gv);
+#endif
             WS_ACC(c_[4], t0_);
             // gh += W3_i^T gphi_i BEFORE the meeting point of the product: the chain gives the four waves ~3 k cycles of
             // slack at barrier B, and gphi (32 registers) is dead by the time the product's fragments are live
@@ -1525,6 +1589,7 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         // ---- trunk backward
 #pragma unroll
         for (int l = L - 1; l >= 1; --l) {
+#ifdef MF_FB_STAGE_BURST
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -1534,6 +1599,13 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             FB_SYNC();                               // the previous product has read S_A / S_B
             stage_tile(myA, lane, gh);
             stage_tile(myB, lane, h[l - 1]);
+#else
+            t1_ = WS_T();
+            if (l == 1) input_layer4(lds + g.offW0, lds + g.offB0, g.S0, xb, h[0], col, hh);
+            FB_SYNC();                               // the previous product has read S_A / S_B
+            stage_tile(myB, lane, h[l - 1]);
+            relu_mask_stage(gh, h[l], myA, lane);
+#endif
             FB_SYNC();
             WS_ACC(c_[12], t1_);
             t1_ = WS_T();
@@ -1567,12 +1639,17 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             WS_ACC(c_[14], t1_);
         }
         t1_ = WS_T();
+#ifdef MF_FB_STAGE_BURST
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) gh[rt][r] = (h[0][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
         FB_SYNC();
         stage_tile(myA, lane, gh);
+#else
+        FB_SYNC();
+        relu_mask_stage(gh, h[0], myA, lane);
+#endif
         stage_x_rows(myB, col, hh, d, xr);                  // S_B rows 0..d-1 <- x (rows >= d: stale finite values, never flushed)
         FB_SYNC();
 #if defined(MF_DW_ASM) && !defined(MF_FB_NO_DW)
