@@ -1421,6 +1421,8 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
 #pragma unroll
             for (int l = 1; l < L; ++l) {
                 const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
+                // (bias by ONE MFMA per tile — A = the bias in k = 0, B = 1, C = 0 — instead of bias_tile's 16 ds_read_b32 and
+                // their exposed round trip was measured in round 3: 16.82 against 16.77 ms per step, not kept)
                 h[l][0] = bias_tile(W + HID * WS, 0, hh);
                 h[l][1] = bias_tile(W + HID * WS, 1, hh);
                 // trunk chains run DENSE here: 8 straight-line groups (64 MFMAs) beat the 5 + 8 mask-bounded groups
@@ -1438,24 +1440,17 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                         default: chain64x2i<1, 8>(h[l][0], h[l][1], w0, w1, bt); break;       // equal ranges: interleaved
                     }
                 }
-#ifdef MF_FB_STAGE_BURST
-                relu2(h[l]);
-#else
                 if (l == L - 1) {
                     FB_SYNC();                           // the previous group's last product has read S_A / S_B
-                    relu2_stage(h[l], myB, lane);
+                    relu2_stage(h[l], myB, lane);        // the stores ride between the ReLUs: no 8 KB burst per wave
                 } else {
                     relu2(h[l]);
                 }
-#endif
             }
             if (L == 1) { h[0][0] = h0[0]; h[0][1] = h0[1]; }
         }
         WS_ACC(c_[0], t0_);
-#ifndef MF_FB_STAGE_BURST
-        if (L == 1)
-#endif
-        {
+        if (L == 1) {
             FB_SYNC();                                   // the previous group's last product has read S_A / S_B
             stage_tile(myB, lane, h[L - 1]);
         }
@@ -1502,15 +1497,14 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
                 gyi = (i == j) ? gyr[j] : gyi;
             }
             float yi, li, gxd;
-#ifndef MF_FB_LATE_BARRIER_A
-            // barrier A ("product i-1 has read S_A") sits AHEAD of the spline: every wave passed product i-1 a whole phi
-            // chain ago, and with nothing between the adjoint and the staging stores the compiler is free to issue each
-            // ds_write as its value is ready — the 32 KB of a staging event then drain through the 64 B/clk LDS write
-            // path underneath the adjoint's VALU work instead of in one burst that all four waves sit through
+            // Barrier A ("product i-1 has read S_A") sits AHEAD of the spline, and the staging stores are issued from inside
+            // the adjoint as each slot becomes final: the 32 KB of a staging event drain through the 64-85 B/clk LDS write
+            // path underneath the adjoint's VALU work instead of as one burst in front of the next chain, whose fragment
+            // reads queue behind it (17.12 -> 16.78 ms per step at C4).
             if (i > 0) FB_SYNC();
-#endif
-#if defined(MF_FB_STAGE_BURST) || defined(MF_FB_NO_SPLINE) || defined(MF_FB_LATE_BARRIER_A)
+#if defined(MF_FB_NO_SPLINE)
             FB_SPLINE(rqs_apply<K, 1>(v, xi, hh, yi, li, gyi, gl, gv, gxd, bins_rt));
+            stage_tile(myA, lane, gv);
 #else
             {
                 float* const qA = myA + lane;
@@ -1522,14 +1516,6 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
 #pragma unroll
             for (int j = 0; j < 4; ++j) gacc[j] += ((hh == ((i >> 2) & 1)) && ((i & 3) == j)) ? gxd : 0.0f;
             t0_ = WS_T();
-#ifdef MF_FB_LATE_BARRIER_A
-            if (i > 0) FB_SYNC();                    // product i-1 has read S_A
-#endif
-            WS_ACC(c_[3], t0_);
-            t0_ = WS_T();
-#if defined(MF_FB_STAGE_BURST) || defined(MF_FB_NO_SPLINE) || defined(MF_FB_LATE_BARRIER_A)
-            stage_tile(myA, lane, gv);
-#endif
             WS_ACC(c_[4], t0_);
             // gh += W3_i^T gphi_i BEFORE the meeting point of the product: the chain gives the four waves ~3 k cycles of
             // slack at barrier B, and gphi (32 registers) is dead by the time the product's fragments are live
@@ -1589,23 +1575,11 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
         // ---- trunk backward
 #pragma unroll
         for (int l = L - 1; l >= 1; --l) {
-#ifdef MF_FB_STAGE_BURST
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gh[rt][r] = (h[l][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
-            t1_ = WS_T();
-            if (l == 1) input_layer4(lds + g.offW0, lds + g.offB0, g.S0, xb, h[0], col, hh);
-            FB_SYNC();                               // the previous product has read S_A / S_B
-            stage_tile(myA, lane, gh);
-            stage_tile(myB, lane, h[l - 1]);
-#else
             t1_ = WS_T();
             if (l == 1) input_layer4(lds + g.offW0, lds + g.offB0, g.S0, xb, h[0], col, hh);
             FB_SYNC();                               // the previous product has read S_A / S_B
             stage_tile(myB, lane, h[l - 1]);
-            relu_mask_stage(gh, h[l], myA, lane);
-#endif
+            relu_mask_stage(gh, h[l], myA, lane);    // ReLU mask fused with the staging stores of the masked gradient
             FB_SYNC();
             WS_ACC(c_[12], t1_);
             t1_ = WS_T();
@@ -1639,17 +1613,8 @@ __global__ __launch_bounds__(FB_BLOCK) void rqs_layer_bwd_fused_kernel(const flo
             WS_ACC(c_[14], t1_);
         }
         t1_ = WS_T();
-#ifdef MF_FB_STAGE_BURST
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gh[rt][r] = (h[0][rt][r] > 0.0f) ? gh[rt][r] : 0.0f;
-        FB_SYNC();
-        stage_tile(myA, lane, gh);
-#else
         FB_SYNC();
         relu_mask_stage(gh, h[0], myA, lane);
-#endif
         stage_x_rows(myB, col, hh, d, xr);                  // S_B rows 0..d-1 <- x (rows >= d: stale finite values, never flushed)
         FB_SYNC();
 #if defined(MF_DW_ASM) && !defined(MF_FB_NO_DW)

@@ -27,5 +27,17 @@ cd $GRAFT_REPO_ROOT && python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_
 python3 bench.py --scaling strong --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_strong_n1.json 2> $OUT/bench_strong_n1.err
 python3 bench.py --workload c5 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c5.json 2> $OUT/bench_c5.err
 MENTFLOW_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline 2> $OUT/bench_2ranks_shared.err | grep "^{" > $OUT/bench_2ranks_shared.json
+for w in c1 c2 c3; do
+  python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+done
+python3 bench.py --workload c3 --per-gpu 25000 --steps 50 --warmup 5 --no-cpu-baseline --meas-samples 200000 > $OUT/bench_c3_25k_eager.json 2> $OUT/bench_c3_25k_eager.err
+python3 bench.py --workload c3 --per-gpu 25000 --steps 50 --warmup 5 --no-cpu-baseline --meas-samples 200000 --graph --fused-adamw > $OUT/bench_c3_25k_graph_fused.json 2> $OUT/bench_c3_25k_graph_fused.err
+echo "other workloads done"
+# in-kernel cycle stamps of the fused backward (diagnostic build) and the timing ablations
+python3 tools/fb_diag.py 2>/dev/null > $OUT/fused_bwd_cycles.txt
+for abl in NO_BARRIER NO_DW NO_SPLINE; do
+  WS_DIAG_FLAGS="-DMF_FB_$abl" python3 tools/fb_diag.py 2>/dev/null | head -18 > $OUT/fused_bwd_ablation_$(echo $abl | tr A-Z a-z).txt
+done
+echo "stamps done"
 echo "${2:-unknown}" > $OUT/commit.txt
 tail -c 1500 $OUT/bench_default.json

@@ -40,6 +40,9 @@ stats = one("stats/**/*kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 for f in ("stats/bench.json", "bench_default.json", "bench_strong_n1.json", "bench_c5.json", "bench_2ranks_shared.json",
+          "bench_c1.json", "bench_c2.json", "bench_c3.json", "bench_c3_25k_eager.json", "bench_c3_25k_graph_fused.json",
+          "fused_bwd_cycles.txt", "fused_bwd_ablation_no_barrier.txt", "fused_bwd_ablation_no_dw.txt",
+          "fused_bwd_ablation_no_spline.txt",
           "c5_stats/bench.json"):
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
