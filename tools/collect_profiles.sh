@@ -39,5 +39,8 @@ for abl in NO_BARRIER NO_DW NO_SPLINE; do
   WS_DIAG_FLAGS="-DMF_FB_$abl" python3 tools/fb_diag.py 2>/dev/null | head -18 > $OUT/fused_bwd_ablation_$(echo $abl | tr A-Z a-z).txt
 done
 echo "stamps done"
+# gpurun merges at most 64 MiB back: keep the summaries the tools read, drop the raw traces and the diagnostic library
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete; find $OUT -name "*domain_stats.csv" -delete
+rm -f $GRAFT_REPO_ROOT/gpurun_out/libmentflow_diag.so
 echo "${2:-unknown}" > $OUT/commit.txt
 tail -c 1500 $OUT/bench_default.json
