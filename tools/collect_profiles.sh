@@ -43,4 +43,11 @@ echo "stamps done"
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete; find $OUT -name "*domain_stats.csv" -delete
 rm -f $GRAFT_REPO_ROOT/gpurun_out/libmentflow_diag.so
 echo "${2:-unknown}" > $OUT/commit.txt
+# condense ON THE BOX (tools/summarise_pmc.py writes profiles/<tag>_* in this scratch copy of the repo) and hand back only the
+# summaries: the raw rocprofv3 counter tables run to tens of MB per pass
+du -sk $OUT/* | sort -n | tail -5
+python3 tools/summarise_pmc.py $TAG > /dev/null
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out/profiles_out
+cp $GRAFT_REPO_ROOT/profiles/${TAG}_* $GRAFT_REPO_ROOT/profiles/traffic.json $GRAFT_REPO_ROOT/gpurun_out/profiles_out/
+rm -rf $OUT
 tail -c 1500 $OUT/bench_default.json
