@@ -24,7 +24,10 @@ constexpr int NUM_CU = 256;   // MI355X: 8 XCDs x 32 CUs
     emu::launch(dim3(grid), dim3(block), (smem), [&]() { kernel(__VA_ARGS__); })
 #define MF_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(((uintptr_t)emu::g_block->dyn_smem + 63) & ~(uintptr_t)63)
 #define MF_ALLOW_DYN_SMEM(kernel, bytes) ((void)0)
+#define MF_WAVES_PER_SIMD(lo, hi)
 #else
+// register budget of a kernel stated as the occupancy it has to keep (waves per SIMD)
+#define MF_WAVES_PER_SIMD(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #define MF_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (smem), (hipStream_t)(stream), __VA_ARGS__)
 #define MF_DYN_SMEM(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_[]; \

@@ -313,8 +313,12 @@ __device__ __forceinline__ constexpr bool kde2d_dead_cell(int i, int j) {
 
 // grid (G, ngroups); workgroup (bx, by): particles [bx * per_wg, ...), projections of group by.
 // LDS: [Pg*Bx*By] u64 image | [Pg*8] V0 | [Pg*8] V1 | [Bx] cx | [By] cy
+// waves_per_eu(8, 8): the kernel is LDS-atomic bound and lives on occupancy (two 1024-thread workgroups per CU).  With the
+// run-time window guard both window variants sit in one kernel and the allocator took 106 SGPRs for it: 7 waves per SIMD,
+// i.e. ONE workgroup per CU, 5.7 -> 6.8 ms at C5.  Capping the wave at the 8-wave budget (30 scalars spill to VGPR lanes,
+// none in the specialised window loop) restores two workgroups per CU (5.6 ms; A/B in profiles/README.md, round 3).
 template <int RT, int BLOCK>   // RT == 4: both radii are 4 (factorised weights, dead corners skipped);  RT == 0: generic
-__global__ __launch_bounds__(BLOCK) void proj_kde2d_fwd_kernel(
+__global__ __launch_bounds__(BLOCK) MF_WAVES_PER_SIMD(8, 8) void proj_kde2d_fwd_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ V0, const float* __restrict__ V1, int P,
     int Pg, const float* __restrict__ coords_x, int Bx, float inv_sx, int Rx, const float* __restrict__ coords_y,
     int By, float inv_sy, int Ry, u64* __restrict__ Sacc, int per_wg, int gshift) {

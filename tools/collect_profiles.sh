@@ -50,4 +50,4 @@ python3 tools/summarise_pmc.py $TAG > /dev/null
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out/profiles_out
 cp $GRAFT_REPO_ROOT/profiles/${TAG}_* $GRAFT_REPO_ROOT/profiles/traffic.json $GRAFT_REPO_ROOT/gpurun_out/profiles_out/
 rm -rf $OUT
-tail -c 1500 $OUT/bench_default.json
+
