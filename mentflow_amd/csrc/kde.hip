@@ -730,10 +730,23 @@ __global__ __launch_bounds__(KDE_BLOCK) void mc_entropy_sums_kernel(const float*
     }
 }
 
-__global__ void entropy_finish_kernel(const double* __restrict__ acc2, int nparts, float* __restrict__ out2) {
+// One wave: lane l sums the partials l, l + 64, ... of both components (independent loads: the serial two-thread version of
+// rounds 1-2 took 100 us for 1 024 partials, a dependent global load each), then the 64 lane sums are added in lane order by
+// lane 0.  Fixed order whatever the timing: the result is reproducible.
+__global__ __launch_bounds__(64) void entropy_finish_kernel(const double* __restrict__ acc2, int nparts,
+                                                            float* __restrict__ out2) {
+    __shared__ double part[2][64];
+    double t0 = 0.0, t1 = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) {
+        t0 += acc2[2 * i];
+        t1 += acc2[2 * i + 1];
+    }
+    part[0][threadIdx.x] = t0;
+    part[1][threadIdx.x] = t1;
+    __syncthreads();
     if (threadIdx.x < 2) {
         double t = 0.0;
-        for (int i = 0; i < nparts; ++i) t += acc2[2 * i + threadIdx.x];
+        for (int l = 0; l < 64; ++l) t += part[threadIdx.x][l];
         out2[threadIdx.x] = (float)t;
     }
 }
