@@ -558,13 +558,21 @@ __global__ __launch_bounds__(BLOCK) void rqs_layer_fwd_kernel(const float* __res
         float xb[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) xb[s] = (2 * s + hh < d) ? xp[2 * s + hh] : 0.0f;
+        // The mask bounds are loop invariants: left alone, the compiler evaluates every "group < bound" test once, ahead of
+        // the tile loop, keeps the 40 results as lane masks in SGPR pairs and re-derives each branch condition from them
+        // with a v_cndmask / v_cmp_ne pair per group (54 VALU instructions per tile).  Opaque copies of the three scalars
+        // keep the tests where they are used: one s_cmp each.
+        int d_s = d, kh0 = sp.kend_h[0], kh1 = sp.kend_h[1];
+#ifndef MF_EMU
+        asm volatile("" : "+s"(d_s), "+s"(kh0), "+s"(kh1));
+#endif
         f32x16_t h[2];
-        input_layer(lds + g.offW0, lds + g.offB0, g.S0, d, xb, h, col, hh);
+        input_layer(lds + g.offW0, lds + g.offB0, g.S0, d_s, xb, h, col, hh);
 #pragma unroll
         for (int l = 1; l < L; ++l) {
             f32x16_t t[2];
             const float* W = lds + g.offWh + (l - 1) * (HID * WS + HID);
-            linear64(W, W + HID * WS, h, t, col, hh, sp.kend_h[0], sp.kend_h[1]);
+            linear64(W, W + HID * WS, h, t, col, hh, kh0, kh1);
             relu2(t);
             h[0] = t[0];
             h[1] = t[1];
