@@ -1,0 +1,48 @@
+// Launchers of the flow-layer kernels, one translation unit per kernel family so that the (long) device compiles of the
+// template instances run in parallel and a change to one family rebuilds one object:
+//   flow.hip            C ABI of the flow layers (argument checks, variant choice, gradient reduce)  -> calls the launchers
+//   flow_fwd.hip        forward kernels (RQS + affine)
+//   flow_bwd_fused.hip  fused backward (+ parameter gradients), compiled once per MF_FUSED_SAVED = 0, 1, 2
+//   flow_bwd2.hip       two-kernel backward + the parameter-gradient contraction (outer_accum)
+//   flow_inv.hip        inverse (density of a point)
+// Every launcher returns 0 once the kernel is enqueued (the caller runs check_launch) and 2 when no instance is built for
+// (bins, hidden_layers); `smem` / `grid` are computed by the caller.
+#pragma once
+#include "flow_kernels.inc"
+
+namespace mf {
+
+// Built spline instances: bins 20 (the reference's value, experiments/setup.py:119-121) and 8 (zuko's default) at compile
+// time; every other 2 <= bins <= 21 through the run-time instance (RQS_ANY: slots laid out for 21 bins, slower).
+#define MF_RQS_CASES(X) X(20, 3) X(20, 2) X(8, 3) X(8, 2) X(RQS_ANY, 3) X(RQS_ANY, 2)
+#define MF_AFFINE_CASES(X) X(3) X(2)
+inline bool rqs_case_matches(int KK, int bins) {
+    return KK == RQS_ANY ? (bins != 20 && bins != 8 && bins >= 2 && bins <= RQS_KMAX) : bins == KK;
+}
+
+constexpr int LAUNCH_NO_INSTANCE = 2;
+
+int launch_rqs_fwd(int bins, int L, int block, int grid, size_t smem, void* stream, const float* image, int d, const float* x,
+                   int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp, const Sparsity& sp);
+int launch_affine_fwd(int L, int grid, size_t smem, void* stream, const float* image, int d, const float* x, int64_t n, float* y,
+                      const float* logp_in, float* logp_out, int init_logp, const Sparsity& sp);
+
+int launch_rqs_bwd_fused_s0(int bins, int L, int grid, size_t smem, void* stream, const float* image, int d, const float* x,
+                            int64_t n, const float* gy, const float* glogp, float* gx, float* gslab, int accumulate,
+                            const Sparsity& sp);
+int launch_affine_bwd_fused(int L, int grid, size_t smem, void* stream, const float* image, int d, const float* x, int64_t n,
+                            const float* gy, const float* glogp, float* gx, float* gslab, int accumulate);
+
+int launch_rqs_bwd2(int bins, int L, int block, int grid, size_t smem, void* stream, const float* image, int d, const float* x,
+                    int64_t n, const float* gy, const float* glogp, float* gx, float* scratch, const Sparsity& sp);
+int launch_affine_bwd2(int L, int grid, size_t smem, void* stream, const float* image, int d, const float* x, int64_t n,
+                       const float* gy, const float* glogp, float* gx, float* scratch, const Sparsity& sp);
+int launch_outer_accum(int grid_x, int nwaves, void* stream, const float* scratch, const float* x, int64_t n, int d, int L,
+                       int nblk, float* gslab, int accumulate, const Sparsity& sp);
+
+int launch_rqs_inv(int bins, int L, int grid, size_t smem, void* stream, const float* image, int d, const float* y, int64_t n,
+                   float* x, const Sparsity& sp, const InvOrder& io);
+int launch_affine_inv(int L, int grid, size_t smem, void* stream, const float* image, int d, const float* y, int64_t n, float* x,
+                      const Sparsity& sp, const InvOrder& io);
+
+}  // namespace mf

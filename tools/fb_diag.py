@@ -8,8 +8,15 @@ csrc = os.path.join(ROOT, "mentflow_amd", "csrc")
 lib = os.path.join(ROOT, "gpurun_out", "libmentflow_diag.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 extra = os.environ.get("WS_DIAG_FLAGS", "").split()
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMF_WS_DIAG", *extra,
-                os.path.join(csrc, "api.hip"), os.path.join(csrc, "kde.hip"), os.path.join(csrc, "flow.hip"), "-o", lib], check=True)
+# every translation unit of SOURCES.txt in one hipcc call (a diagnostic build: compile time does not matter here)
+tus = [l.split() for l in open(os.path.join(csrc, "SOURCES.txt")) if l.strip() and not l.startswith("#")]
+objs = []
+for name, src, *flags in tus:
+    obj = os.path.join(os.path.dirname(lib), f"diag_{name}.o")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DMF_WS_DIAG", *flags, *extra, "-c",
+                    os.path.join(csrc, src), "-o", obj], check=True)
+    objs.append(obj)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib], check=True)
 import torch
 from mentflow_amd import _lib
 _lib.use_library(lib)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Development tool: per-kernel register / spill / LDS / occupancy report of flow.hip (or $1) from hipcc's own remarks.
-SRC=${1:-mentflow_amd/csrc/flow.hip}; shift
+# Development tool: per-kernel register / spill / LDS / occupancy report of one translation unit (default flow_bwd_fused.hip; or $1, extra flags after it) from hipcc's own remarks.
+SRC=${1:-mentflow_amd/csrc/flow_bwd_fused.hip}; shift
 cd "$(dirname "$0")/.."
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$SRC" -o /dev/null --cuda-device-only \
     -Rpass-analysis=kernel-resource-usage "$@" 2>&1 | python3 -c "
