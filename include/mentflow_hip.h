@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 3
+#define MF_ABI_VERSION 4
 #define MF_ENTROPY_SCRATCH_DOUBLES 2048
 
 int mf_abi_version(void);
@@ -85,6 +85,27 @@ int mf_flow_bwd_slab_rows(int64_t n, int d, int hidden_layers, const int32_t* or
 int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
                           const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gslab,
                           int slab_rows, int accumulate, float* scratch, int64_t scratch_floats, void* stream);
+
+/* Activation hand-off from the training forward to the fused backward (ABI 4).  The eager reference keeps every activation
+ * of zuko's conditioner for autograd (reached from mentflow/generate/flows/zuko.py:24-26).  mf_flow_rqs_layer_fwd recomputes
+ * nothing and saves nothing (evaluation / no-grad); mf_flow_rqs_layer_fwd_save is the same forward that ALSO writes, per
+ * 32-particle tile, the conditioner's activations into `act` in the register layout of the fused backward kernel:
+ *   level 1: the `hidden_layers` post-ReLU hidden tiles                (64 floats per particle and level:  768 B at L = 3)
+ *   level 2: level 1 + the d x 64 conditioner outputs (spline logits)  (+ 256 d B per particle:          2 304 B at d = 6)
+ * and mf_flow_rqs_layer_bwd_saved is the fused backward that loads them instead of re-running the conditioner's forward
+ * chains (a quarter of that MFMA-bound kernel).  `act` holds mf_flow_rqs_act_floats(n, d, hidden_layers, level) floats per
+ * layer and belongs to ONE (layer, batch) pair: forward writes it, the backward of the same layer and particles reads it.
+ * mf_flow_rqs_act_level(...) = highest level the built kernels take for the configuration under the current backward variant:
+ * 2 with `order`, d <= 6 and bins in {20, 8}; 0 otherwise (two-kernel backward, run-time-bins instance) — callers then use
+ * mf_flow_rqs_layer_fwd / _bwd.  Gradients are bitwise identical at every level (same arithmetic on the same values).      */
+int mf_flow_rqs_act_level(int d, int hidden_layers, int bins, const int32_t* order);
+int64_t mf_flow_rqs_act_floats(int64_t n, int d, int hidden_layers, int level);
+int mf_flow_rqs_layer_fwd_save(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
+                               const float* x, int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp,
+                               float* act, int64_t act_floats, int level, void* stream);
+int mf_flow_rqs_layer_bwd_saved(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
+                                const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gslab,
+                                int slab_rows, int accumulate, const float* act, int64_t act_floats, int level, void* stream);
 
 /* Sum of the slab rows, all layers in one launch: gslab[layers][rows][image_floats] ->
  * gflat[j] = sum_{r < rows} gslab[t][r][pos] with grad_index[j] = t * image_floats + pos (-1: parameter without an

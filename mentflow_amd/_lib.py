@@ -34,6 +34,12 @@ PROTOTYPES = {
     "mf_flow_set_bwd_variant": (_i32, [_i32]),
     "mf_flow_bwd_scratch_floats": (_i64, [_i64, _i32, _i32, _ptr]),
     "mf_flow_rqs_layer_fwd": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32, _ptr]),
+    "mf_flow_rqs_act_level": (_i32, [_i32, _i32, _i32, _ptr]),
+    "mf_flow_rqs_act_floats": (_i64, [_i64, _i32, _i32, _i32]),
+    "mf_flow_rqs_layer_fwd_save": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32, _ptr, _i64, _i32,
+                                          _ptr]),
+    "mf_flow_rqs_layer_bwd_saved": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr,
+                                           _i64, _i32, _ptr]),
     "mf_flow_bwd_slab_rows": (_i32, [_i64, _i32, _i32, _ptr]),
     "mf_flow_rqs_layer_bwd": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr, _i64,
                                      _ptr]),
@@ -85,7 +91,7 @@ def use_library(path: str) -> None:
     """Load a specific build of the C-ABI library (tests only)."""
     global _lib, _device_type
     lib = _bind(C.CDLL(path))
-    if lib.mf_abi_version() != 3:
+    if lib.mf_abi_version() != 4:
         raise LibraryError(f"ABI version mismatch in {path}")
     _lib = lib
     _device_type = "cpu" if lib.mf_is_emulation() else "cuda"

@@ -81,9 +81,45 @@ extern "C" int mf_flow_rqs_deriv_slot(int bins) {
     return (bins >= 2 && bins <= RQS_KMAX) ? RQS_KMAX : -1;
 }
 
+// ---- activation hand-off (forward -> fused backward through HBM; act_store in flow_kernels.inc) --------------------------
+// highest level the built kernels can take for this configuration under the CURRENT backward variant: 2 when the call takes the
+// fused backward with a compile-time spline instance, else 0 (two-kernel path, d = 7, no order, run-time bins)
+extern "C" int mf_flow_rqs_act_level(int d, int hidden_layers, int bins, const int32_t* order) {
+    if (order == nullptr || d < 1 || d > FLOW_DMAX || !rqs_saved_instance(bins, hidden_layers)) return 0;
+    size_t smem;
+    return rqs_bwd_fused(1, d, hidden_layers, order, make_sparsity(d, order, d), &smem) ? 2 : 0;
+}
+extern "C" int64_t mf_flow_rqs_act_floats(int64_t n, int d, int hidden_layers, int level) {
+    if (n <= 0 || level < 1 || level > 2) return 0;
+    return ((n + 31) / 32) * (int64_t)act_blocks(d, hidden_layers, level) * ACT_BLOCK;
+}
+
+static int rqs_layer_fwd_impl(const float* image, int d, int hidden_layers, int bins, const int32_t* order, const float* x,
+                              int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp, float* act, int level,
+                              void* stream);
+
 extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
                                       const float* x, int64_t n, float* y, const float* logp_in, float* logp_out,
                                       int init_logp, void* stream) {
+    return rqs_layer_fwd_impl(image, d, hidden_layers, bins, order, x, n, y, logp_in, logp_out, init_logp, nullptr, 0, stream);
+}
+
+extern "C" int mf_flow_rqs_layer_fwd_save(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
+                                           const float* x, int64_t n, float* y, const float* logp_in, float* logp_out,
+                                           int init_logp, float* act, int64_t act_floats, int level, void* stream) {
+    if (level < 1 || level > 2) return fail("mf_flow_rqs_layer_fwd_save: level must be 1 or 2 (got %d)", level);
+    if (level > mf_flow_rqs_act_level(d, hidden_layers, bins, order))
+        return fail("no backward kernel consumes saved activations for d=%d hidden_layers=%d bins=%d (mf_flow_rqs_act_level)", d,
+                    hidden_layers, bins);
+    if (n > 0 && (act == nullptr || act_floats < mf_flow_rqs_act_floats(n, d, hidden_layers, level)))
+        return fail("act buffer too small: %lld floats, need %lld (mf_flow_rqs_act_floats)", (long long)act_floats,
+                    (long long)mf_flow_rqs_act_floats(n, d, hidden_layers, level));
+    return rqs_layer_fwd_impl(image, d, hidden_layers, bins, order, x, n, y, logp_in, logp_out, init_logp, act, level, stream);
+}
+
+static int rqs_layer_fwd_impl(const float* image, int d, int hidden_layers, int bins, const int32_t* order, const float* x,
+                              int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp, float* act, int level,
+                              void* stream) {
     if (flow_check(d, hidden_layers, n)) return 1;
     if (n == 0) return 0;
     const Sparsity sp = make_sparsity(d, order, d);
@@ -96,7 +132,7 @@ extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layer
     if (fwd_block != 256 && fwd_block != 512 && fwd_block != 1024) return fail("MENTFLOW_FWD_BLOCK must be 256, 512 or 1024");
     ProfScope prof(PK_FLOW_FWD, stream);
     if (launch_rqs_fwd(bins, hidden_layers, fwd_block, flow_grid(n, fwd_block / 64), smem, stream, image, d, x, n, y, logp_in,
-                       logp_out, init_logp, sp))
+                       logp_out, init_logp, sp, act, level))
         return no_rqs_instance(bins, hidden_layers);
     return check_launch("mf_flow_rqs_layer_fwd");
 }
@@ -104,7 +140,13 @@ extern "C" int mf_flow_rqs_layer_fwd(const float* image, int d, int hidden_layer
 // grid sizes of the backward kernels: the number of slab rows a call writes (one per workgroup column)
 static int fused_grid(int64_t n) {
     const int64_t ngroups = ((n + 31) / 32 + 3) / 4;
-    return (int)(ngroups > NUM_CU ? NUM_CU : (ngroups < 1 ? 1 : ngroups));
+    int64_t cap = NUM_CU;
+#ifdef MF_EMU
+    // emulator build only (tests): a small cap makes a workgroup walk several groups at test sizes, which exercises the
+    // cross-group prefetches (particle rows, handed-over activations) that a 256-workgroup grid only reaches past 32 768 particles
+    if (const char* e = getenv("MENTFLOW_EMU_FUSED_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
+#endif
+    return (int)(ngroups > cap ? cap : (ngroups < 1 ? 1 : ngroups));
 }
 static int outer_accum_grid(int64_t n) {
     static const int oa_mult = [] { const char* e = getenv("MENTFLOW_OA_MULT"); return e ? atoi(e) : 2; }();
@@ -124,6 +166,30 @@ extern "C" int mf_flow_bwd_slab_rows(int64_t n, int d, int hidden_layers, const 
     return outer_accum_grid(n);
 }
 
+extern "C" int mf_flow_rqs_layer_bwd_saved(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
+                                            const float* x, int64_t n, const float* gy, const float* glogp, float* gx,
+                                            float* gslab, int slab_rows, int accumulate, const float* act, int64_t act_floats,
+                                            int level, void* stream) {
+    if (flow_check(d, hidden_layers, n)) return 1;
+    if (n == 0) return 0;
+    if (level < 1 || level > 2) return fail("mf_flow_rqs_layer_bwd_saved: level must be 1 or 2 (got %d)", level);
+    if (level > mf_flow_rqs_act_level(d, hidden_layers, bins, order))
+        return fail("no backward kernel consumes saved activations for d=%d hidden_layers=%d bins=%d (mf_flow_rqs_act_level)", d,
+                    hidden_layers, bins);
+    if (act == nullptr || act_floats < mf_flow_rqs_act_floats(n, d, hidden_layers, level)) return fail("act buffer too small");
+    const Sparsity sp = make_sparsity(d, order, d);
+    size_t smem_f = 0;
+    if (!rqs_bwd_fused(n, d, hidden_layers, order, sp, &smem_f)) return fail("the saved-activation backward is the fused kernel");
+    if (slab_rows != fused_grid(n)) return fail("gslab has %d rows, this call writes %d (mf_flow_bwd_slab_rows)", slab_rows, fused_grid(n));
+    ProfScope prof(PK_FLOW_BWD, stream);
+    const int rc = level == 1 ? launch_rqs_bwd_fused_s1(bins, hidden_layers, fused_grid(n), smem_f, stream, image, d, x, n, gy, glogp,
+                                                        gx, gslab, accumulate, sp, act)
+                              : launch_rqs_bwd_fused_s2(bins, hidden_layers, fused_grid(n), smem_f, stream, image, d, x, n, gy, glogp,
+                                                        gx, gslab, accumulate, sp, act);
+    if (rc) return no_rqs_instance(bins, hidden_layers);
+    return check_launch("mf_flow_rqs_layer_bwd_saved");
+}
+
 extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
                                       const float* x, int64_t n, const float* gy, const float* glogp, float* gx,
                                       float* gslab, int slab_rows, int accumulate, float* scratch, int64_t scratch_floats,
@@ -140,7 +206,7 @@ extern "C" int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layer
     if (rqs_bwd_fused(n, d, hidden_layers, order, sp, &smem_f)) {
         ProfScope prof(PK_FLOW_BWD, stream);
         if (launch_rqs_bwd_fused_s0(bins, hidden_layers, fused_grid(n), smem_f, stream, image, d, x, n, gy, glogp, gx, gslab,
-                                    accumulate, sp))
+                                    accumulate, sp, nullptr))
             return no_rqs_instance(bins, hidden_layers);
         return check_launch("mf_flow_rqs_layer_bwd(fused)");
     }

@@ -4,12 +4,13 @@
 namespace mf {
 
 int launch_rqs_fwd(int bins, int L, int block, int grid, size_t smem, void* stream, const float* image, int d, const float* x,
-                   int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp, const Sparsity& sp) {
+                   int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp, const Sparsity& sp, float* act,
+                   int act_level) {
 #define XB(KK, LL, BB)                                                                                                \
     if (block == BB) {                                                                                                \
         MF_ALLOW_DYN_SMEM((rqs_layer_fwd_kernel<KK, LL, BB>), smem);                                                  \
         MF_LAUNCH((rqs_layer_fwd_kernel<KK, LL, BB>), grid, BB, smem, stream, image, d, x, n, y, logp_in, logp_out,   \
-                  init_logp, sp, bins);                                                                               \
+                  init_logp, sp, bins, act, act_level);                                                               \
         return 0;                                                                                                     \
     }
 #define X(KK, LL)                                                                                                     \

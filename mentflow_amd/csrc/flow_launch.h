@@ -2,7 +2,7 @@
 // template instances run in parallel and a change to one family rebuilds one object:
 //   flow.hip            C ABI of the flow layers (argument checks, variant choice, gradient reduce)  -> calls the launchers
 //   flow_fwd.hip        forward kernels (RQS + affine)
-//   flow_bwd_fused.hip  fused backward (+ parameter gradients), compiled once per MF_FUSED_SAVED = 0, 1, 2
+//   flow_bwd_fused.hip  fused backward (+ parameter gradients), compiled once per hand-off level MF_FUSED_SAVED = 0, 1, 2
 //   flow_bwd2.hip       two-kernel backward + the parameter-gradient contraction (outer_accum)
 //   flow_inv.hip        inverse (density of a point)
 // Every launcher returns 0 once the kernel is enqueued (the caller runs check_launch) and 2 when no instance is built for
@@ -23,13 +23,21 @@ inline bool rqs_case_matches(int KK, int bins) {
 constexpr int LAUNCH_NO_INSTANCE = 2;
 
 int launch_rqs_fwd(int bins, int L, int block, int grid, size_t smem, void* stream, const float* image, int d, const float* x,
-                   int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp, const Sparsity& sp);
+                   int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp, const Sparsity& sp, float* act,
+                   int act_level);
 int launch_affine_fwd(int L, int grid, size_t smem, void* stream, const float* image, int d, const float* x, int64_t n, float* y,
                       const float* logp_in, float* logp_out, int init_logp, const Sparsity& sp);
 
-int launch_rqs_bwd_fused_s0(int bins, int L, int grid, size_t smem, void* stream, const float* image, int d, const float* x,
-                            int64_t n, const float* gy, const float* glogp, float* gx, float* gslab, int accumulate,
-                            const Sparsity& sp);
+// one function per hand-off level (MF_FUSED_SAVED = 0, 1, 2: separate objects); levels 1 and 2 are built for the compile-time
+// spline instances only (bins 20 and 8)
+#define MF_DECL_FUSED(S)                                                                                              \
+    int launch_rqs_bwd_fused_s##S(int bins, int L, int grid, size_t smem, void* stream, const float* image, int d,    \
+                                  const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gslab, \
+                                  int accumulate, const Sparsity& sp, const float* act);
+MF_DECL_FUSED(0) MF_DECL_FUSED(1) MF_DECL_FUSED(2)
+#undef MF_DECL_FUSED
+#define MF_RQS_SAVED_CASES(X) X(20, 3) X(20, 2) X(8, 3) X(8, 2)
+inline bool rqs_saved_instance(int bins, int L) { return (bins == 20 || bins == 8) && (L == 2 || L == 3); }
 int launch_affine_bwd_fused(int L, int grid, size_t smem, void* stream, const float* image, int d, const float* x, int64_t n,
                             const float* gy, const float* glogp, float* gx, float* gslab, int accumulate);
 

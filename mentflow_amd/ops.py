@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -16,6 +17,7 @@ from . import _lib
 from ._lib import call, ptr, stream_ptr
 
 _F32 = torch.float32
+_ENV_ACT_LEVEL = int(os.environ["MENTFLOW_ACT_LEVEL"]) if os.environ.get("MENTFLOW_ACT_LEVEL", "") != "" else None
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -43,13 +45,37 @@ class FlowSpec:
         self.image_index = image_index      # int32 [T * image_floats]  -> flat parameter index or -1
         self.grad_index = grad_index        # int32 [numel]             -> position in the image stack or -1
         self.bwd_chunk = 1 << 20            # particles per backward chunk (3 KiB of scratch each at d=6)
+        # Activation hand-off from the training forward to the fused backward through HBM (mf_flow_rqs_layer_fwd_save):
+        # None = the highest level (2: hidden tiles + conditioner outputs, 1: hidden tiles, 0: recompute everything) that the
+        # kernels support for this flow AND whose buffers (T layers x 2 304 / 768 B per particle at d = 6, L = 3) fit
+        # `act_budget_bytes`; an int pins the level (tests, A/B runs).  Environment: MENTFLOW_ACT_LEVEL.
+        self.act_level: Optional[int] = _ENV_ACT_LEVEL
+        self.act_budget_bytes: Optional[int] = None     # None: 60 % of the device's memory (173 GB on an MI355X)
+        self._act_supported: Optional[int] = None
+
+    def resolve_act_level(self, n: int, device: torch.device) -> int:
+        if self.kind != "rqs" or not self.sparse or n <= 0:
+            return 0
+        lib = _lib.get_lib()
+        supported = min(lib.mf_flow_rqs_act_level(self.d, self.L, self.bins, o) for o in self.orders)
+        want = supported if self.act_level is None else min(int(self.act_level), supported)
+        budget = self.act_budget_bytes
+        if budget is None:
+            budget = int(0.6 * torch.cuda.get_device_properties(device).total_memory) if device.type == "cuda" else 1 << 62
+        while want > 0 and 4 * self.T * lib.mf_flow_rqs_act_floats(n, self.d, self.L, want) > budget:
+            want -= 1
+        return want
 
 
 def _layer_fwd(spec: FlowSpec, t: int, image: torch.Tensor, x: torch.Tensor, y: torch.Tensor,
-               logp_in: Optional[torch.Tensor], logp_out: torch.Tensor, init: bool) -> None:
+               logp_in: Optional[torch.Tensor], logp_out: torch.Tensor, init: bool, act: Optional[torch.Tensor] = None,
+               act_level: int = 0) -> None:
     n = x.shape[0]
     order = spec.orders[t] if spec.sparse else None
-    if spec.kind == "rqs":
+    if act_level > 0:
+        call("mf_flow_rqs_layer_fwd_save", ptr(image), spec.d, spec.L, spec.bins, order, ptr(x), n, ptr(y), ptr(logp_in),
+             ptr(logp_out), int(init), ptr(act), act.numel(), int(act_level), stream_ptr(x))
+    elif spec.kind == "rqs":
         call("mf_flow_rqs_layer_fwd", ptr(image), spec.d, spec.L, spec.bins, order, ptr(x), n, ptr(y), ptr(logp_in),
              ptr(logp_out), int(init), stream_ptr(x))
     else:
@@ -57,11 +83,15 @@ def _layer_fwd(spec: FlowSpec, t: int, image: torch.Tensor, x: torch.Tensor, y: 
              ptr(logp_out), int(init), stream_ptr(x))
 
 
-def _layer_bwd(spec: FlowSpec, t: int, image, x, gy, glogp, gx, gslab, accumulate: bool, scratch) -> None:
+def _layer_bwd(spec: FlowSpec, t: int, image, x, gy, glogp, gx, gslab, accumulate: bool, scratch, act=None,
+               act_level: int = 0) -> None:
     n = x.shape[0]
     order = spec.orders[t] if spec.sparse else None
     rows = gslab.shape[0]
-    if spec.kind == "rqs":
+    if act_level > 0:
+        call("mf_flow_rqs_layer_bwd_saved", ptr(image), spec.d, spec.L, spec.bins, order, ptr(x), n, ptr(gy), ptr(glogp),
+             ptr(gx), ptr(gslab), rows, int(accumulate), ptr(act), act.numel(), int(act_level), stream_ptr(x))
+    elif spec.kind == "rqs":
         call("mf_flow_rqs_layer_bwd", ptr(image), spec.d, spec.L, spec.bins, order, ptr(x), n, ptr(gy), ptr(glogp),
              ptr(gx), ptr(gslab), rows, int(accumulate), ptr(scratch), scratch.numel(), stream_ptr(x))
     else:
@@ -108,7 +138,9 @@ class FlowSampleFn(torch.autograd.Function):
 
     Replaces zuko ``NormalizingFlow.rsample_and_log_prob`` as called by
     mentflow/generate/flows/zuko.py:24-26 (base draw z injected) and its autograd backward.
-    Saved for backward: the T layer inputs (N x d each) and the packed images; everything else is recomputed.
+    Saved for backward: the T layer inputs (N x d each), the packed images and — FlowSpec.act_level — the conditioner's
+    hidden tiles / outputs of every layer, written by the forward kernels in the register layout of the fused backward
+    (the eager reference keeps every activation for autograd; level 0 recomputes them in the backward instead).
 
     Two ways to receive the parameter gradient: (a) ``flat`` is an autograd tensor (e.g. ``torch.cat`` of the parameters):
     its gradient is returned to autograd; (b) ``flat`` is a plain buffer, ``trigger`` a leaf that requires grad (so that
@@ -124,14 +156,20 @@ class FlowSampleFn(torch.autograd.Function):
         n = z.shape[0]
         images = pack_images(spec, flat)
         logp = torch.empty(n, dtype=_F32, device=z.device)
+        level = spec.resolve_act_level(n, z.device)
+        act = None
+        if level > 0:
+            act = torch.empty(spec.T, _lib.get_lib().mf_flow_rqs_act_floats(n, spec.d, spec.L, level), dtype=_F32, device=z.device)
         xs = [z]
         for t in range(spec.T):
             y = torch.empty_like(z)
-            _layer_fwd(spec, t, images[t], xs[-1], y, logp, logp, t == 0)
+            _layer_fwd(spec, t, images[t], xs[-1], y, logp, logp, t == 0, None if act is None else act[t], level)
             xs.append(y)
         ctx.spec = spec
         ctx.grad_reduce = grad_reduce
         ctx.grad_sink = grad_sink
+        ctx.act_level = level
+        ctx.act = act                       # written once by the forward kernels, read once by the backward: not an autograd tensor
         ctx.save_for_backward(images, *xs[:-1])
         return xs[-1], logp
 
@@ -144,6 +182,10 @@ class FlowSampleFn(torch.autograd.Function):
         gx = torch.zeros(n, spec.d, dtype=_F32, device=dev) if gx is None else _f32c(gx)
         glogp = torch.zeros(n, dtype=_F32, device=dev) if glogp is None else _f32c(glogp)
         chunk, scratch_floats, rows_of = _bwd_plan(spec, n)
+        level, act = ctx.act_level, ctx.act
+        if level > 0 and chunk != n:
+            raise RuntimeError("the backward variant changed between forward and backward: the saved activations belong to the "
+                               "fused kernel (mf_flow_set_bwd_variant)")
         scratch = torch.empty(max(scratch_floats, 1), dtype=_F32, device=dev)
         # chunks grouped by the number of slab rows they write (at most two groups: full chunks and a ragged last one)
         spans = [(a, min(n, a + chunk)) for a in range(0, n, chunk)]
@@ -159,7 +201,7 @@ class FlowSampleFn(torch.autograd.Function):
             for r, members in groups.items():
                 for k, (a, b) in enumerate(members):
                     _layer_bwd(spec, t, images[t], xs[t][a:b], g[a:b], glogp[a:b], None if gprev is None else gprev[a:b],
-                               slabs[r][t], k > 0, scratch)
+                               slabs[r][t], k > 0, scratch, None if act is None else act[t], level)
             g = gprev
         for r, slab in slabs.items():
             part = torch.empty(spec.grad_index.numel(), dtype=_F32, device=dev)

@@ -59,6 +59,26 @@ static void flow_rqs(int d, int L, int K, int64_t n, bool fused) {
     CK(mf_flow_rqs_layer_bwd(image.data(), d, L, K, order.data(), x.data(), n, gy.data(), gl.data(), nullptr, slab.data(), rows,
                              1, scratch.data(), (int64_t)scratch.size(), nullptr));
     all_finite(gx, "rqs gx");
+    // activation hand-off (ABI 4): forward that saves, backward that loads; exactly-sized buffer (ASan guards its end), and the
+    // parameter-gradient slab must come out bit for bit as the recompute backward wrote it
+    const int lvl_max = mf_flow_rqs_act_level(d, L, K, order.data());
+    for (int level = 1; level <= lvl_max; ++level) {
+        const int64_t af = mf_flow_rqs_act_floats(n, d, L, level);
+        std::vector<float> act((size_t)af, NAN), y2(n * d), logp2(n), gx2(n * d), slab2((size_t)rows * F, NAN);
+        CK(mf_flow_rqs_layer_fwd_save(image.data(), d, L, K, order.data(), x.data(), n, y2.data(), nullptr, logp2.data(), 1,
+                                      act.data(), af, level, nullptr));
+        all_finite(act, "rqs act");
+        CK(mf_flow_rqs_layer_bwd_saved(image.data(), d, L, K, order.data(), x.data(), n, gy.data(), gl.data(), gx2.data(),
+                                       slab2.data(), rows, 0, act.data(), af, level, nullptr));
+        std::vector<float> slab1((size_t)rows * F, NAN);
+        CK(mf_flow_rqs_layer_bwd(image.data(), d, L, K, order.data(), x.data(), n, gy.data(), gl.data(), gx.data(), slab1.data(),
+                                 rows, 0, scratch.data(), (int64_t)scratch.size(), nullptr));
+        if (memcmp(gx.data(), gx2.data(), gx.size() * sizeof(float)) != 0 ||
+            memcmp(slab1.data(), slab2.data(), slab1.size() * sizeof(float)) != 0) {
+            fprintf(stderr, "activation hand-off level %d differs from the recompute backward (d=%d L=%d K=%d)\n", level, d, L, K);
+            exit(4);
+        }
+    }
     // reduce through an identity index over the first layer's image: every slot a parameter can map to must have been
     // written by every workgroup (NaN-initialised slab: an unwritten slot shows up here) — restricted to the slots the
     // packing really uses is the Python side's job; here: finite where written

@@ -32,7 +32,7 @@ def test_header_symbols_are_exported_by_the_gfx950_library(hip_library):
         assert hasattr(lib, name), f"{name} declared in include/mentflow_hip.h but not exported"
     lib.mf_abi_version.restype = ctypes.c_int
     lib.mf_is_emulation.restype = ctypes.c_int
-    assert lib.mf_abi_version() == 3
+    assert lib.mf_abi_version() == 4
     assert lib.mf_is_emulation() == 0                 # the product library is the real thing
     # the code object really is gfx950
     blob = open(hip_library, "rb").read()
