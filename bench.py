@@ -40,6 +40,13 @@ PEAK_HBM = 8000.0              # GB/s spec
 LDS_ATOMIC_U64_PER_CLK_CU = 3.9
 CLOCK_GHZ = 2.4
 NUM_CU = 256
+# KDE backward kernels: bound by vector-instruction ISSUE, not by HBM (76 GB/s of row traffic).  Instruction mix of the inner
+# loop body per (particle, projection) and lane, counted in the gfx950 ISA by tools/isa_loop_mix.py
+# (profiles/r04_kde_bwd_instruction_mix.txt): (full-rate VALU, transcendental, LDS).  A wave64 instruction holds its SIMD-32 for
+# 2 cycles, a transcendental one for 8 (/opt/skills/guides/MI355X_MICROARCH.md, per-instruction cycle constants); the LDS reads
+# (2 cycles per ds_read_b32 on the CU's one LDS) stay under the VALU time of the four SIMDs and are reported, not booked.
+KDE_BWD_MIX = {"kde1d_bwd": (168, 9, 20), "kde2d_bwd": (500, 18, 87)}
+VALU_CYCLES, TRANS_CYCLES, SIMDS = 2, 8, 4 * NUM_CU
 
 WORKLOADS = {
     # name: build_problem kwargs + per-GPU batch (weak scaling) + global batch (strong scaling)
@@ -83,6 +90,8 @@ def parse_args(argv=None):
     ap.add_argument("--global-batch", type=int, default=None,
                     help="with --scaling strong: the global particle count divided over the ranks (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong-n1", action="store_true",
+                    help="skip the extra `strong_n1` object of the default N = 1 line (C4's full 16 777 216 particles on one GPU)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--bwd-chunk", type=int, default=None, help="particles per flow-backward chunk (tuning)")
     ap.add_argument("--meas-samples", type=int, default=1_000_000, help="ground-truth samples behind the measurements")
@@ -327,7 +336,7 @@ def kde_issued_atomics(prob, x, cap: int = 8192):
     return total
 
 
-def traffic_from_profile(dom: str, workload: str, per_gpu: int, fused_bwd: bool):
+def traffic_from_profile(dom: str, workload: str, per_gpu: int, fused_bwd: bool, act_level: int = 0):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json,
     written by tools/summarise_pmc.py).  A constant of that profiled run, NOT a measurement of this one: reported only
     when workload, per-GPU batch and backward variant are the ones that were profiled, with its provenance."""
@@ -339,11 +348,30 @@ def traffic_from_profile(dom: str, workload: str, per_gpu: int, fused_bwd: bool)
     meta = t.get("_meta", {})
     if meta.get("workload", "c4") != workload or int(meta.get("per_gpu", 2_097_152)) != per_gpu:
         return None, None
-    if bool(meta.get("fused_bwd", True)) != fused_bwd or dom not in t:
+    if bool(meta.get("fused_bwd", True)) != fused_bwd or int(meta.get("act_level", 0)) != act_level or dom not in t:
         return None, None
     src = {"file": "profiles/traffic.json", "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, builder run "
            "(FETCH_SIZE x2 on gfx950); constant of that run, not measured by this one", **meta}
     return t[dom], src
+
+
+def pipe_util_from_profile(name: str, workload: str, per_gpu: int, act_level: int):
+    """Fraction of the SIMD cycles in which the matrix pipe was busy (SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE / 8 x 1024
+    SIMDs), from the committed rocprofv3 PMC pass — the dense-equivalent `frac` counts the FLOPs of the masked-out blocks the
+    kernels skip, this is what the pipe really did.  Like `traffic` a constant of the profiled run, reported with provenance
+    and only for the workload / batch / hand-off level that was profiled."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None, None
+    meta = t.get("_meta", {})
+    pu = t.get("_mfma_pipe_busy", {})
+    if (meta.get("workload", "c4") != workload or int(meta.get("per_gpu", 2_097_152)) != per_gpu
+            or int(meta.get("act_level", 0)) != act_level or name not in pu):
+        return None, None
+    return pu[name], {"file": "profiles/traffic.json", "how": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, builder run: "
+                      "busy cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); constant of that run", **meta}
 
 
 def run_worker(args) -> int:
@@ -389,6 +417,8 @@ def run_worker(args) -> int:
         per_gpu, global_batch = weak_per_gpu, weak_per_gpu * world
     prob = build_problem(device=device, penalty_parameter=500.0, meas_samples=args.meas_samples, **w)  # same seed: same weights
     model = prob.model
+    gspec = model.generator.spec() if hasattr(model.generator, "spec") else None
+    act_level = gspec.resolve_act_level(per_gpu, device) if gspec is not None else 0
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0, capturable=bool(args.graph),
                             **({"fused": True} if args.fused_adamw else {}))                             # experiments/setup.py:166-170
     torch.manual_seed(1234 + rank)                                           # every rank draws its own particles
@@ -460,6 +490,47 @@ def run_worker(args) -> int:
     final_loss = float(L.detach())
     total_steps = args.steps * len(region_s)
 
+    # The metric's own full-size configuration in the same record: C4's GLOBAL batch (16 777 216 particles, the N = 1 point of
+    # the strong-scaling series; experiments/rec_nd_1d/run_gmm.sh:32-41 scaled as BASELINE C4) on this one GPU, a few steps
+    # after the timed regions.  `value` stays the weak point above; this object is information.
+    strong_n1 = None
+    if (world == 1 and rank == 0 and not emulated and not args.graph and not args.no_strong_n1 and args.workload == "c4"
+            and args.scaling == "weak" and not args.per_gpu):
+        try:
+            big = strong_global
+            big_level = gspec.resolve_act_level(big, device) if gspec is not None else 0
+            sn_steps, sn_warm = 3, 1
+
+            def big_step():
+                opt.zero_grad()
+                Lb, _, _ = model.loss(big)
+                Lb.backward()
+                opt.step()
+                return Lb
+
+            for _ in range(sn_warm):
+                big_step()
+            _lib.prof_enable(True)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(sn_steps):
+                Lb = big_step()
+            sync()
+            el_b = time.perf_counter() - t0
+            prof_b = _lib.prof_report()
+            _lib.prof_enable(False)
+            strong_n1 = {"workload": "c4 at its global batch on ONE GPU (the N = 1 point of --scaling strong)", "global_batch": big,
+                         "steps": sn_steps, "warmup": sn_warm, "ms_per_step": el_b / sn_steps * 1e3,
+                         "value": big * sn_steps / el_b, "unit": "particle-samples/s", "activation_handoff_level": big_level,
+                         "kernel_ms_per_step": {k: v[0] / sn_steps for k, v in prof_b.items() if v[1] > 0},
+                         "peak_memory_GB": torch.cuda.max_memory_allocated(device) / 1e9, "final_loss": float(Lb.detach())}
+            del Lb
+            torch.cuda.empty_cache()
+        except Exception as exc:                                  # information only: never fail the headline run for it
+            _lib.prof_enable(False)
+            strong_n1 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        log("strong_n1: " + json.dumps(strong_n1))
+
     rc = 0
     if rank == 0:
         order = sorted(range(len(region_s)), key=lambda i: region_s[i])
@@ -488,6 +559,11 @@ def run_worker(args) -> int:
             "config": {"workload": f"{args.workload}: {desc}", "global_batch": global_batch, "per_gpu_batch": per_gpu,
                        "parallelism": f"dp{world} (particle batch sharded; 2 all-reduces/step)",
                        "step": "zero_grad + MENTFlow.loss + backward + AdamW.step" + (" (hipGraph replay)" if args.graph else ""),
+                       "activation_handoff": {"level": act_level, "meaning": "0 = the backward recomputes the conditioner; 1 = the "
+                                              "forward hands its hidden tiles to the backward through HBM; 2 = also the "
+                                              "conditioner outputs (mf_flow_rqs_layer_fwd_save / _bwd_saved)",
+                                              "bytes_per_particle_and_layer": (4 * _lib.get_lib().mf_flow_rqs_act_floats(
+                                                  32, gspec.d, gspec.L, gspec.bins, act_level) // 32) if act_level else 0},
                        "final_loss": final_loss},
         }
         kernels = {k: v for k, v in prof.items() if v[1] > 0}
@@ -526,10 +602,21 @@ def run_worker(args) -> int:
                                                        f"counted on 8192 of the model's particles, weights >= 2^-50) x "
                                                        f"{int(per_launch_particles)} particles",
                                 hbm_GBps=4 * d * per_launch_particles / avg_s / 1e9)
-                else:   # KDE backward: row reads + writes
-                    nbytes = 8 * d * per_launch_particles
-                    roof.update(bound="hbm", unit="GB/s", peak=PEAK_HBM, achieved=nbytes / avg_s / 1e9,
-                                algorithmic_per_launch=f"{8 * d} B/particle x {int(per_launch_particles)} particles")
+                else:
+                    # KDE backward: per particle and projection a 9-term (9 x 9 in 2-D) window of exp / gather / FMA work and
+                    # 8 d bytes of row traffic per particle (76 GB/s at C4: two orders under HBM).  What bounds it is vector
+                    # issue: the loop body's instruction mix (KDE_BWD_MIX, from the ISA) against the SIMDs' issue capacity.
+                    nv, nt, nl = KDE_BWD_MIX[name]
+                    simd_cycles = VALU_CYCLES * nv + TRANS_CYCLES * nt            # per wave (64 lanes) and projection
+                    pp = P * per_launch_particles                                 # particle-projections per launch
+                    peak = SIMDS * CLOCK_GHZ * 64 / simd_cycles                   # G particle-projections / s
+                    roof.update(bound="valu_issue", unit="G particle-projections/s", peak=peak, achieved=pp / avg_s / 1e9,
+                                peak_source=f"{nv} full-rate VALU x {VALU_CYCLES} cycles + {nt} transcendental x {TRANS_CYCLES} "
+                                            f"cycles per wave64 and projection (inner loop of the gfx950 ISA, tools/isa_loop_mix.py, "
+                                            f"profiles/r04_kde_bwd_instruction_mix.txt) on {SIMDS} SIMDs at {CLOCK_GHZ} GHz; "
+                                            f"{nl} LDS reads per lane ride along (not booked)",
+                                algorithmic_per_launch=f"{P} projections x {int(per_launch_particles)} particles",
+                                hbm_GBps=8 * d * per_launch_particles / avg_s / 1e9)
                 roof["frac"] = roof["achieved"] / roof["peak"]
                 roof["avg_launch_ms"] = ms / cnt
                 roof["launches"] = cnt
@@ -538,14 +625,22 @@ def run_worker(args) -> int:
             # dominant kernel by summed HIP-event time inside the timed regions
             dom = max(kernels, key=lambda k: kernels[k][0])
             roof = kernel_roofline(dom)
-            roof["traffic"], roof["traffic_source"] = traffic_from_profile(dom, args.workload, per_gpu, fused_bwd)
+            roof["traffic"], roof["traffic_source"] = traffic_from_profile(dom, args.workload, per_gpu, fused_bwd, act_level)
             out["roofline"] = roof
             # the same accounting for every timed kernel (the dominant one is `roofline`)
             out["kernel_rooflines"] = {k: {q: v for q, v in kernel_roofline(k).items()
-                                           if q in ("bound", "unit", "peak", "achieved", "frac", "avg_launch_ms", "algorithmic_per_launch")}
+                                           if q in ("bound", "unit", "peak", "achieved", "frac", "avg_launch_ms",
+                                                    "algorithmic_per_launch", "peak_source", "hbm_GBps")}
                                        for k in kernels}
+            # `frac` of the MFMA-bound kernels is DENSE-EQUIVALENT (FLOPs as the reference computes them): the kernels skip
+            # the MFMAs of all-zero mask blocks, so a frac of 0.9 does not mean the pipe is 90 % busy.  What the pipe did:
+            for k, r in list(out["kernel_rooflines"].items()) + [(dom, roof)]:
+                if r.get("bound") == "mfma":
+                    r["mfma_pipe_busy"], r["mfma_pipe_busy_source"] = pipe_util_from_profile(k, args.workload, per_gpu, act_level)
             out["step_mfma_frac"] = 3 * T * lf * (value / world) / (PEAK_MFMA_F32 * 1e12)
             out["kernel_ms_per_step"] = {k: v[0] / total_steps for k, v in kernels.items()}
+        if strong_n1 is not None:
+            out["strong_n1"] = strong_n1
         log("gpu leg: " + json.dumps({k: out.get(k) for k in ("value", "ms_per_step", "timed_regions", "roofline",
                                                               "kernel_ms_per_step")}))
         if world > 1 and ranks_seen != world:

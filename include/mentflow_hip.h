@@ -87,19 +87,22 @@ int mf_flow_rqs_layer_bwd(const float* image, int d, int hidden_layers, int bins
                           int slab_rows, int accumulate, float* scratch, int64_t scratch_floats, void* stream);
 
 /* Activation hand-off from the training forward to the fused backward (ABI 4).  The eager reference keeps every activation
- * of zuko's conditioner for autograd (reached from mentflow/generate/flows/zuko.py:24-26).  mf_flow_rqs_layer_fwd recomputes
- * nothing and saves nothing (evaluation / no-grad); mf_flow_rqs_layer_fwd_save is the same forward that ALSO writes, per
- * 32-particle tile, the conditioner's activations into `act` in the register layout of the fused backward kernel:
- *   level 1: the `hidden_layers` post-ReLU hidden tiles                (64 floats per particle and level:  768 B at L = 3)
- *   level 2: level 1 + the d x 64 conditioner outputs (spline logits)  (+ 256 d B per particle:          2 304 B at d = 6)
+ * of zuko's conditioner for autograd (reached from mentflow/generate/flows/zuko.py:24-26).  mf_flow_rqs_layer_fwd saves nothing
+ * (evaluation / no-grad; its backward mf_flow_rqs_layer_bwd recomputes the conditioner); mf_flow_rqs_layer_fwd_save is the same
+ * forward that ALSO writes, per 32-particle tile, conditioner activations into `act` in the register layout of the fused
+ * backward kernel:
+ *   level 1: the post-ReLU hidden tiles of levels 1 .. hidden_layers-1 (level 0 is 8 MFMAs from the layer input: recomputed)
+ *            64 floats per particle and level:                                                  512 B at hidden_layers = 3
+ *   level 2: level 1 + the conditioner outputs (spline logits) of the d-1 features that have a conditioner, the 3 bins / 2
+ *            slots per lane half the spline reads:                            + 240 (d-1) B at 20 bins: 1 712 B at d = 6
  * and mf_flow_rqs_layer_bwd_saved is the fused backward that loads them instead of re-running the conditioner's forward
- * chains (a quarter of that MFMA-bound kernel).  `act` holds mf_flow_rqs_act_floats(n, d, hidden_layers, level) floats per
- * layer and belongs to ONE (layer, batch) pair: forward writes it, the backward of the same layer and particles reads it.
+ * chains (a quarter of that MFMA-bound kernel).  `act` holds mf_flow_rqs_act_floats(n, d, hidden_layers, bins, level) floats
+ * per layer and belongs to ONE (layer, batch) pair: forward writes it, the backward of the same layer and particles reads it.
  * mf_flow_rqs_act_level(...) = highest level the built kernels take for the configuration under the current backward variant:
  * 2 with `order`, d <= 6 and bins in {20, 8}; 0 otherwise (two-kernel backward, run-time-bins instance) — callers then use
  * mf_flow_rqs_layer_fwd / _bwd.  Gradients are bitwise identical at every level (same arithmetic on the same values).      */
 int mf_flow_rqs_act_level(int d, int hidden_layers, int bins, const int32_t* order);
-int64_t mf_flow_rqs_act_floats(int64_t n, int d, int hidden_layers, int level);
+int64_t mf_flow_rqs_act_floats(int64_t n, int d, int hidden_layers, int bins, int level);
 int mf_flow_rqs_layer_fwd_save(const float* image, int d, int hidden_layers, int bins, const int32_t* order,
                                const float* x, int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp,
                                float* act, int64_t act_floats, int level, void* stream);

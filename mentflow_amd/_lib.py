@@ -35,7 +35,7 @@ PROTOTYPES = {
     "mf_flow_bwd_scratch_floats": (_i64, [_i64, _i32, _i32, _ptr]),
     "mf_flow_rqs_layer_fwd": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32, _ptr]),
     "mf_flow_rqs_act_level": (_i32, [_i32, _i32, _i32, _ptr]),
-    "mf_flow_rqs_act_floats": (_i64, [_i64, _i32, _i32, _i32]),
+    "mf_flow_rqs_act_floats": (_i64, [_i64, _i32, _i32, _i32, _i32]),
     "mf_flow_rqs_layer_fwd_save": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32, _ptr, _i64, _i32,
                                           _ptr]),
     "mf_flow_rqs_layer_bwd_saved": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr,

@@ -89,9 +89,10 @@ extern "C" int mf_flow_rqs_act_level(int d, int hidden_layers, int bins, const i
     size_t smem;
     return rqs_bwd_fused(1, d, hidden_layers, order, make_sparsity(d, order, d), &smem) ? 2 : 0;
 }
-extern "C" int64_t mf_flow_rqs_act_floats(int64_t n, int d, int hidden_layers, int level) {
-    if (n <= 0 || level < 1 || level > 2) return 0;
-    return ((n + 31) / 32) * (int64_t)act_blocks(d, hidden_layers, level) * ACT_BLOCK;
+extern "C" int64_t mf_flow_rqs_act_floats(int64_t n, int d, int hidden_layers, int bins, int level) {
+    if (n <= 0 || d < 1 || hidden_layers < 1 || level < 1 || level > 2) return 0;
+    const int phif = bins == 20 ? phi_floats<20>() : (bins == 8 ? phi_floats<8>() : phi_floats<RQS_ANY>());
+    return ((n + 31) / 32) * (int64_t)act_tile_floats(hidden_layers, level, d - 1, phif);     // d - 1 features have a conditioner
 }
 
 static int rqs_layer_fwd_impl(const float* image, int d, int hidden_layers, int bins, const int32_t* order, const float* x,
@@ -111,9 +112,9 @@ extern "C" int mf_flow_rqs_layer_fwd_save(const float* image, int d, int hidden_
     if (level > mf_flow_rqs_act_level(d, hidden_layers, bins, order))
         return fail("no backward kernel consumes saved activations for d=%d hidden_layers=%d bins=%d (mf_flow_rqs_act_level)", d,
                     hidden_layers, bins);
-    if (n > 0 && (act == nullptr || act_floats < mf_flow_rqs_act_floats(n, d, hidden_layers, level)))
+    if (n > 0 && (act == nullptr || act_floats < mf_flow_rqs_act_floats(n, d, hidden_layers, bins, level)))
         return fail("act buffer too small: %lld floats, need %lld (mf_flow_rqs_act_floats)", (long long)act_floats,
-                    (long long)mf_flow_rqs_act_floats(n, d, hidden_layers, level));
+                    (long long)mf_flow_rqs_act_floats(n, d, hidden_layers, bins, level));
     return rqs_layer_fwd_impl(image, d, hidden_layers, bins, order, x, n, y, logp_in, logp_out, init_logp, act, level, stream);
 }
 
@@ -176,7 +177,7 @@ extern "C" int mf_flow_rqs_layer_bwd_saved(const float* image, int d, int hidden
     if (level > mf_flow_rqs_act_level(d, hidden_layers, bins, order))
         return fail("no backward kernel consumes saved activations for d=%d hidden_layers=%d bins=%d (mf_flow_rqs_act_level)", d,
                     hidden_layers, bins);
-    if (act == nullptr || act_floats < mf_flow_rqs_act_floats(n, d, hidden_layers, level)) return fail("act buffer too small");
+    if (act == nullptr || act_floats < mf_flow_rqs_act_floats(n, d, hidden_layers, bins, level)) return fail("act buffer too small");
     const Sparsity sp = make_sparsity(d, order, d);
     size_t smem_f = 0;
     if (!rqs_bwd_fused(n, d, hidden_layers, order, sp, &smem_f)) return fail("the saved-activation backward is the fused kernel");

@@ -47,7 +47,7 @@ class FlowSpec:
         self.bwd_chunk = 1 << 20            # particles per backward chunk (3 KiB of scratch each at d=6)
         # Activation hand-off from the training forward to the fused backward through HBM (mf_flow_rqs_layer_fwd_save):
         # None = the highest level (2: hidden tiles + conditioner outputs, 1: hidden tiles, 0: recompute everything) that the
-        # kernels support for this flow AND whose buffers (T layers x 2 304 / 768 B per particle at d = 6, L = 3) fit
+        # kernels support for this flow AND whose buffers (T layers x 1 712 / 512 B per particle at d = 6, L = 3, 20 bins) fit
         # `act_budget_bytes`; an int pins the level (tests, A/B runs).  Environment: MENTFLOW_ACT_LEVEL.
         self.act_level: Optional[int] = _ENV_ACT_LEVEL
         self.act_budget_bytes: Optional[int] = None     # None: 60 % of the device's memory (173 GB on an MI355X)
@@ -62,7 +62,7 @@ class FlowSpec:
         budget = self.act_budget_bytes
         if budget is None:
             budget = int(0.6 * torch.cuda.get_device_properties(device).total_memory) if device.type == "cuda" else 1 << 62
-        while want > 0 and 4 * self.T * lib.mf_flow_rqs_act_floats(n, self.d, self.L, want) > budget:
+        while want > 0 and 4 * self.T * lib.mf_flow_rqs_act_floats(n, self.d, self.L, self.bins, want) > budget:
             want -= 1
         return want
 
@@ -159,7 +159,7 @@ class FlowSampleFn(torch.autograd.Function):
         level = spec.resolve_act_level(n, z.device)
         act = None
         if level > 0:
-            act = torch.empty(spec.T, _lib.get_lib().mf_flow_rqs_act_floats(n, spec.d, spec.L, level), dtype=_F32, device=z.device)
+            act = torch.empty(spec.T, _lib.get_lib().mf_flow_rqs_act_floats(n, spec.d, spec.L, spec.bins, level), dtype=_F32, device=z.device)
         xs = [z]
         for t in range(spec.T):
             y = torch.empty_like(z)

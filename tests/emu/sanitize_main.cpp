@@ -63,7 +63,7 @@ static void flow_rqs(int d, int L, int K, int64_t n, bool fused) {
     // parameter-gradient slab must come out bit for bit as the recompute backward wrote it
     const int lvl_max = mf_flow_rqs_act_level(d, L, K, order.data());
     for (int level = 1; level <= lvl_max; ++level) {
-        const int64_t af = mf_flow_rqs_act_floats(n, d, L, level);
+        const int64_t af = mf_flow_rqs_act_floats(n, d, L, K, level);
         std::vector<float> act((size_t)af, NAN), y2(n * d), logp2(n), gx2(n * d), slab2((size_t)rows * F, NAN);
         CK(mf_flow_rqs_layer_fwd_save(image.data(), d, L, K, order.data(), x.data(), n, y2.data(), nullptr, logp2.data(), 1,
                                       act.data(), af, level, nullptr));

@@ -2,8 +2,11 @@
 mf_flow_rqs_layer_bwd_saved, include/mentflow_hip.h ABI 4).  The reference keeps every conditioner activation for autograd
 (mentflow/generate/flows/zuko.py:24-26 -> zuko MaskedMLP); level 0 recomputes them in the backward, levels 1 / 2 load what the
 forward stored.  Every level evaluates the same fp32 arithmetic on the same values (an fp32 MFMA chain is an exact, k-ordered
-fma chain; the extra k-steps of a dense chain multiply masked-out zeros), so x, log_prob and EVERY gradient must agree BIT FOR
-BIT across levels — and, through test_flow_kernels.py's oracle comparisons of the default level, with the oracle."""
+fma chain; the extra k-steps of a dense chain multiply masked-out zeros), so x and log_prob (one forward kernel) must agree BIT
+FOR BIT and so must every gradient in the emulator build (compiled without floating-point contraction).  On the GPU the three
+backward instances are separate compilations of the spline adjoint under hipcc's default -ffp-contract=fast, which fuses
+multiply-adds across statements differently per instance: gradients there agree to fp32 rounding (measured 2e-7 of the largest
+entry; gate 2e-6).  Through test_flow_kernels.py's oracle comparisons of the default level all levels are tied to the oracle."""
 import pytest
 import torch
 
@@ -39,7 +42,11 @@ def test_levels_agree_bitwise(backend, d, bins, hidden_layers, n):
     for level in (1, 2):
         out = _run(backend, d, bins, hidden_layers, n, level)
         for name, a, b in zip(("x", "log_prob", "parameter gradients", "dL/dz"), ref, out):
-            assert torch.equal(a, b), f"level {level}: {name} differs from the recompute backward, max |diff| {float((a - b).abs().max()):.3e}"
+            err = float((a - b).abs().max())
+            if backend.type == "cuda" and name in ("parameter gradients", "dL/dz"):
+                assert err <= 2e-6 * float(a.abs().max()), f"level {level}: {name} off by {err:.3e} (largest entry {float(a.abs().max()):.3e})"
+            else:
+                assert torch.equal(a, b), f"level {level}: {name} differs from the recompute backward, max |diff| {err:.3e}"
 
 
 def test_level_resolution_and_fallbacks(backend):
@@ -50,9 +57,11 @@ def test_level_resolution_and_fallbacks(backend):
                                       hidden_units=64, transforms=2, bins=20)
     spec = gen.spec()
     assert spec.resolve_act_level(1000, backend) == 2
-    per_layer2 = 4 * lib.mf_flow_rqs_act_floats(1000, 6, 3, 2)
-    per_layer1 = 4 * lib.mf_flow_rqs_act_floats(1000, 6, 3, 1)
-    assert per_layer2 == 32 * 9 * 2048 * 4 and per_layer1 == 32 * 3 * 2048 * 4      # 32 tiles x (L + d | L) blocks
+    per_layer2 = 4 * lib.mf_flow_rqs_act_floats(1000, 6, 3, 20, 2)
+    per_layer1 = 4 * lib.mf_flow_rqs_act_floats(1000, 6, 3, 20, 1)
+    # 32 tiles x 32 particles x (2 hidden levels x 64 floats [+ 5 features x 2 lane halves x 30 slots])
+    assert per_layer1 == 32 * 32 * 2 * 64 * 4 and per_layer2 == per_layer1 + 32 * 32 * 5 * 60 * 4
+    assert 4 * lib.mf_flow_rqs_act_floats(1000, 3, 2, 8, 2) == 32 * 32 * (64 + 2 * 24) * 4
     spec.act_budget_bytes = 2 * per_layer2 - 1
     assert spec.resolve_act_level(1000, backend) == 1
     spec.act_budget_bytes = 2 * per_layer1 - 1
@@ -82,7 +91,7 @@ def test_save_entry_points_check_their_arguments(backend):
     n = 100
     x = torch.randn(n, 4, device=backend)
     y, lp = torch.empty_like(x), torch.empty(n, device=backend)
-    need = lib.mf_flow_rqs_act_floats(n, 4, 3, 2)
+    need = lib.mf_flow_rqs_act_floats(n, 4, 3, 20, 2)
     small = torch.empty(need - 1, device=backend)
     with pytest.raises(RuntimeError, match="act buffer too small"):
         ops._layer_fwd(spec, 0, images[0], x, y, lp, lp, True, small, 2)

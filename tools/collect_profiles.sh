@@ -7,14 +7,14 @@ TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT/stats $OUT/fetch $OUT/write $OUT/sq
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-strong-n1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats/bench.json 2> $OUT/stats/err.txt
 echo "stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > /dev/null 2> $OUT/fetch/err.txt
 echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > /dev/null 2> $OUT/write/err.txt
 echo "write done"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq -- $BENCH > /dev/null 2> $OUT/sq/err.txt
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- $BENCH > /dev/null 2> $OUT/sq/err.txt
 echo "sq done"
 # C5 (2-D KDE dominant after the flow): kernel stats + SQ counters
 mkdir -p $OUT/c5_stats $OUT/c5_sq
@@ -34,9 +34,15 @@ python3 bench.py --workload c3 --per-gpu 25000 --steps 50 --warmup 5 --no-cpu-ba
 python3 bench.py --workload c3 --per-gpu 25000 --steps 50 --warmup 5 --no-cpu-baseline --meas-samples 200000 --graph --fused-adamw > $OUT/bench_c3_25k_graph_fused.json 2> $OUT/bench_c3_25k_graph_fused.err
 echo "other workloads done"
 # in-kernel cycle stamps of the fused backward (diagnostic build) and the timing ablations
-python3 tools/fb_diag.py 2>/dev/null > $OUT/fused_bwd_cycles.txt
+for lv in 0 1 2; do
+  FB_DIAG_LEVEL=$lv python3 tools/fb_diag.py 2>/dev/null >> $OUT/fused_bwd_cycles.txt
+done
 for abl in NO_BARRIER NO_DW NO_SPLINE; do
-  WS_DIAG_FLAGS="-DMF_FB_$abl" python3 tools/fb_diag.py 2>/dev/null | head -18 > $OUT/fused_bwd_ablation_$(echo $abl | tr A-Z a-z).txt
+  FB_DIAG_LEVEL=2 WS_DIAG_FLAGS="-DMF_FB_$abl" python3 tools/fb_diag.py 2>/dev/null | head -18 > $OUT/fused_bwd_ablation_$(echo $abl | tr A-Z a-z).txt
+done
+# the hand-off levels side by side (one bench line each) and the batch sweep of the strong-scaling series
+for lv in 0 1 2; do
+  MENTFLOW_ACT_LEVEL=$lv python3 bench.py --steps 20 --warmup 3 --repeats 3 --no-cpu-baseline --no-strong-n1 > $OUT/bench_level$lv.json 2> $OUT/bench_level$lv.err
 done
 echo "stamps done"
 # gpurun merges at most 64 MiB back: keep the summaries the tools read, drop the raw traces and the diagnostic library

@@ -7,7 +7,9 @@ sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "mentflow_amd", "csrc")
 lib = os.path.join(ROOT, "gpurun_out", "libmentflow_diag.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
-extra = os.environ.get("WS_DIAG_FLAGS", "").split()
+level = int(os.environ.get("FB_DIAG_LEVEL", "0"))        # activation hand-off level whose kernel is stamped (0, 1, 2)
+os.environ["MENTFLOW_ACT_LEVEL"] = str(level)
+extra = os.environ.get("WS_DIAG_FLAGS", "").split() + [f"-DMF_WS_DIAG_LEVEL={level}"]
 # every translation unit of SOURCES.txt in one hipcc call (a diagnostic build: compile time does not matter here)
 tus = [l.split() for l in open(os.path.join(csrc, "SOURCES.txt")) if l.strip() and not l.startswith("#")]
 objs = []
@@ -37,9 +39,9 @@ assert h.mf_debug_ws_read(raw) == 0
 aw = np.array(raw, dtype=np.float64).reshape(256, 4, 16)      # [workgroup][wave][slot]
 a = aw[:, 0, :]
 groups = (n // 32) / 4 / 256
-names = ["trunk fwd", "phi = W3 h (x d)", "rqs_apply (x d)", "barrier A (x d)", "stage gv (x d)", "barrier B (x d)",
+names = ["trunk fwd / loads+stage", "phi = W3 h | v wait (x d)", "rqs_apply (x d)", "barrier A (x d)", "stage gv (x d)", "barrier B (x d)",
          "dW last layer (x d)", "final flush (x groups!)", "gh += W3^T gv (x d)", "trunk bwd + dW", "gx", "TOTAL", " trunk: stage+barriers", " trunk: dW (x2)", " trunk: W^T chains (x2)", " level 0: stage + dW"]
-print("groups per workgroup:", groups, " (ticks of s_memtime = shader cycles)")
+print(f"hand-off level {level}; groups per workgroup:", groups, " (ticks of s_memtime = shader cycles)")
 for q, nm in enumerate(names):
     print(f"  {nm:24s} {a[:, q].mean() / groups:9.1f} ticks per group   {100 * a[:, q].mean() / a[:, 11].mean():5.1f} %")
 

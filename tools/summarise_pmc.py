@@ -42,7 +42,7 @@ if stats:
 for f in ("stats/bench.json", "bench_default.json", "bench_strong_n1.json", "bench_c5.json", "bench_2ranks_shared.json",
           "bench_c1.json", "bench_c2.json", "bench_c3.json", "bench_c3_25k_eager.json", "bench_c3_25k_graph_fused.json",
           "fused_bwd_cycles.txt", "fused_bwd_ablation_no_barrier.txt", "fused_bwd_ablation_no_dw.txt",
-          "fused_bwd_ablation_no_spline.txt",
+          "fused_bwd_ablation_no_spline.txt", "bench_level0.json", "bench_level1.json", "bench_level2.json",
           "c5_stats/bench.json"):
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
@@ -78,11 +78,28 @@ if fetch and write:
     # provenance: bench.py reports these numbers only for the workload / batch / backward variant that was profiled
     meta = {"workload": "c4", "per_gpu": 2097152, "fused_bwd": True, "tag": tag,
             "command": "python3 bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline"}
+    try:      # the activation hand-off level the profiled bench ran at (bench.py echoes it in its line)
+        bj = json.loads(open(os.path.join(src, "stats", "bench.json")).read().strip().splitlines()[-1])
+        meta["act_level"] = int(bj["config"]["activation_handoff"]["level"])
+    except Exception:
+        meta["act_level"] = 0
     try:
         meta["commit"] = open(os.path.join(src, "commit.txt")).read().strip()
     except OSError:
         pass
     traffic["_meta"] = meta
+    # matrix-pipe utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the SIMDs) against the SIMD cycles of the
+    # same dispatches, GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs (MI355X_MICROARCH.md: the counter is the sum over the 8 XCDs)
+    sqf = one("sq/**/*counter_collection.csv")
+    if sqf:
+        busy, act = collections.defaultdict(float), collections.defaultdict(float)
+        for r in csv.DictReader(open(sqf)):
+            k = short(r["Kernel_Name"])
+            if k and r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                busy[k] += float(r["Counter_Value"])
+            if k and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                act[k] += float(r["Counter_Value"])
+        traffic["_mfma_pipe_busy"] = {k: busy[k] / (act[k] / 8.0 * 1024.0) for k in busy if act.get(k, 0) > 0 and busy[k] > 0}
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 
 c5stats = one("c5_stats/**/*kernel_stats.csv")
