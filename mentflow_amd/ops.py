@@ -169,20 +169,22 @@ class FlowSampleFn(torch.autograd.Function):
         ctx.grad_reduce = grad_reduce
         ctx.grad_sink = grad_sink
         ctx.act_level = level
-        ctx.act = act                       # written once by the forward kernels, read once by the backward: not an autograd tensor
-        ctx.save_for_backward(images, *xs[:-1])
+        # a SAVED tensor, so that autograd releases it with the graph right after backward (kept as a plain attribute it lived as
+        # long as the loss tensor of the step: two 18 GB buffers alive at C4, and no room for the 16 M-particle batch)
+        ctx.save_for_backward(images, act if act is not None else images.new_empty(0), *xs[:-1])
         return xs[-1], logp
 
     @staticmethod
     def backward(ctx, gx: Optional[torch.Tensor], glogp: Optional[torch.Tensor]):
         spec: FlowSpec = ctx.spec
-        images, *xs = ctx.saved_tensors
+        images, act, *xs = ctx.saved_tensors
         n = xs[0].shape[0]
         dev = images.device
         gx = torch.zeros(n, spec.d, dtype=_F32, device=dev) if gx is None else _f32c(gx)
         glogp = torch.zeros(n, dtype=_F32, device=dev) if glogp is None else _f32c(glogp)
         chunk, scratch_floats, rows_of = _bwd_plan(spec, n)
-        level, act = ctx.act_level, ctx.act
+        level = ctx.act_level
+        act = act if level > 0 else None
         if level > 0 and chunk != n:
             raise RuntimeError("the backward variant changed between forward and backward: the saved activations belong to the "
                                "fused kernel (mf_flow_set_bwd_variant)")
