@@ -133,6 +133,10 @@ def launch_ranks(args, argv) -> int:
                 c.wait(timeout=max(0.1, deadline - time.time()))
             except subprocess.TimeoutExpired:
                 c.kill()
+                try:
+                    c.wait(timeout=10)                # reap the killed rank: no zombie holding its GPU context open
+                except subprocess.TimeoutExpired:
+                    pass
         if sig_name:
             log(f"launcher: {sig_name} received, {len(children)} ranks stopped")
 
@@ -154,7 +158,16 @@ def launch_ranks(args, argv) -> int:
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             env.setdefault("OMP_NUM_THREADS", "4")
             out = subprocess.PIPE if r == 0 else sys.stderr
-            children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+            # SIGTERM / SIGINT stay blocked from the fork until the child is in `children`: a signal that lands in between would
+            # otherwise be handled by a reap() that does not know the rank just started.  A signal mask survives fork AND exec,
+            # so the child restores the launcher's previous mask itself before it execs (the launcher is single-threaded and
+            # has imported neither torch nor HIP: preexec_fn is safe here).
+            blocked = signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM, signal.SIGINT})
+            try:
+                children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out,
+                                                 preexec_fn=lambda: signal.pthread_sigmask(signal.SIG_SETMASK, blocked)))
+            finally:
+                signal.pthread_sigmask(signal.SIG_SETMASK, blocked)
         log(f"launcher: started {n} ranks (pids {[c.pid for c in children]}), rendezvous 127.0.0.1:{port}")
         pending = set(range(n))
         while pending:

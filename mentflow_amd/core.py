@@ -36,6 +36,7 @@ class MENTFlow(nn.Module):
         self.penalty_parameter = penalty_parameter
         self._plan = None
         self._plan_key = None
+        self._no_plan_key = None
         self._generic_logged = False
 
     def set_diagnostics(self, diagnostics):
@@ -98,9 +99,13 @@ class MENTFlow(nn.Module):
             return None
         key = (tuple(id(t) for t in self.transforms), tuple(id(d) for d in unravel(self.diagnostics)),
                tuple(id(m) for m in unravel(self.measurements)),
-               tuple((d.kde, d.noise and d.noise_scale > 0.0) for d in unravel(self.diagnostics)))
+               tuple((getattr(d, "kde", None), bool(getattr(d, "noise", False)) and getattr(d, "noise_scale", 0.0) > 0.0)
+                     for d in unravel(self.diagnostics)))
         if self._plan is not None and self._plan_key == key:
             return self._plan
+        if self._no_plan_key == key:     # "no fused plan" is cached too: the generic loop re-derives nothing per call
+            return None
+        self._no_plan_key = key          # (cleared again below if a plan is found)
         groups, generic = group_measurements(self.transforms, self.diagnostics)
         if generic:                      # a transport / diagnostic outside the fused kernels: the generic loop of loss()
             return None
@@ -118,7 +123,7 @@ class MENTFlow(nn.Module):
             meas = torch.stack([self.measurements[i][j] for (i, j) in slots]).to(torch.float32)
             meas = meas.reshape(len(slots), -1).contiguous()
             plan.append((diagnostic, stacked, meas, [order[s] for s in slots], pre))
-        self._plan, self._plan_key = (plan, pos, kind), key
+        self._plan, self._plan_key, self._no_plan_key = (plan, pos, kind), key, None
         return self._plan
 
     def loss(self, batch_size: int) -> Tuple[torch.Tensor, torch.Tensor, List[torch.Tensor]]:
@@ -129,11 +134,11 @@ class MENTFlow(nn.Module):
         if plan is None:
             # generic loop of the reference (core.py:113-117): any nn.Module transport, any diagnostic, any discrepancy
             # callable; simulate.forward still takes the fused kernels for the pairs they cover
-            if mfdist.is_active():
-                raise NotImplementedError("data-parallel loss needs the fused path (KDE histograms, kld/mae/mse)")
             if not self._generic_logged:
                 self._generic_logged = True
                 log.info("MENTFlow.loss: generic path (sample -> simulate.forward -> discrepancy_function per measurement)")
+            if mfdist.is_active():
+                return self._loss_generic_data_parallel(int(batch_size))
             x, H = self.sample_and_entropy(batch_size)
             predictions = forward(x, self.transforms, self.diagnostics)
             D = self.discrepancy_vector(predictions)
@@ -192,6 +197,34 @@ class MENTFlow(nn.Module):
         L = H + self.penalty_parameter * (D_sum / n_meas)
         return (L, H, D_slots)
 
+    def _loss_generic_data_parallel(self, n_total: int):
+        """The generic loop (core.py:113-117) with the particle batch sharded over the ranks: every histogram diagnostic is a
+        sum over particles followed by a normalisation, so the ranks all-reduce the raw sums of ALL measurements (and the two
+        entropy sums) in ONE buffer and evaluate normalisation, discrepancy callable and loss redundantly — (L, H, D) are
+        the single-process values on the concatenated batch, identical on every rank.  A diagnostic or an entropy estimator
+        without a sum form raises, naming itself."""
+        from .simulate.simulate import raw_sums
+        self._wire_gradient_reduction()
+        x, log_prob = self.generator.sample_and_log_prob(mfdist.local_batch(n_total))
+        est = self.entropy_estimator
+        use_entropy = isinstance(est, MonteCarloEntropyEstimator)
+        if not use_entropy and not isinstance(est, EmptyEntropyEstimator):
+            raise NotImplementedError(f"data-parallel loss: {type(est).__name__} has no sum form to reduce over the ranks "
+                                      "(MonteCarloEntropyEstimator and EmptyEntropyEstimator do)")
+        if use_entropy and log_prob is None:
+            raise ValueError("the Monte-Carlo entropy estimator needs a generator with a density (log_prob is None)")
+        pieces, finish = raw_sums(x, self.transforms, self.diagnostics)
+        shapes = [p.shape for p in pieces]
+        flat = [p.reshape(-1) for p in pieces]
+        if use_entropy:
+            flat.append(ops.EntropySumsFn.apply(x, log_prob))
+        reduced = torch.split(mfdist.all_reduce_sum(torch.cat(flat)), [f.numel() for f in flat])
+        predictions = finish([r.reshape(sh) for r, sh in zip(reduced, shapes)], n_total)
+        D = self.discrepancy_vector(predictions)
+        H = est.from_sums(reduced[-1], n_total) if use_entropy else torch.zeros((), dtype=torch.float32, device=x.device)
+        L = H + self.penalty_parameter * (sum(D) / len(D))
+        return (L, H, D)
+
     # ------------------------------------------------------------------ parameters / checkpoints (core.py:119-159)
     def parameters(self) -> Iterator[nn.Parameter]:
         return self.generator.parameters()
@@ -234,5 +267,5 @@ class MENTFlow(nn.Module):
         prior = getattr(self.entropy_estimator, "prior", None)
         if prior is not None and hasattr(prior, "to"):
             prior.to(device)
-        self._plan = None
+        self._plan = self._plan_key = self._no_plan_key = None
         return self

@@ -55,13 +55,26 @@ class Histogram(Diagnostic):
     def projection_rows(self, matrix: torch.Tensor) -> List[torch.Tensor]:
         raise NotImplementedError
 
-    def batched(self, x: torch.Tensor, rows: List[torch.Tensor]) -> torch.Tensor:
+    # A histogram is a SUM over particles followed by a normalisation: raw_sums(x, rows) are the per-projection sums of the
+    # particles at hand (kernel sums for kde=True, bin counts otherwise), from_sums(S, n) finishes [P, bins...] histograms from
+    # sums over n particles.  batched = from_sums(raw_sums); a data-parallel run all-reduces the sums in between
+    # (MENTFlow.loss, simulate.raw_sums).
+    def raw_sums(self, x: torch.Tensor, rows: List[torch.Tensor]) -> torch.Tensor:
         raise NotImplementedError
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def from_sums(self, S: torch.Tensor, n_total: int) -> torch.Tensor:
+        raise NotImplementedError
+
+    def identity_rows(self, x: torch.Tensor) -> List[torch.Tensor]:
         eye = torch.eye(x.shape[1], dtype=x.dtype, device=x.device)
-        rows = [r[None, :] for r in self.projection_rows(eye)]
-        return self._apply_noise(self.batched(x, rows)[0])
+        return [r[None, :] for r in self.projection_rows(eye)]
+
+    def batched(self, x: torch.Tensor, rows: List[torch.Tensor]) -> torch.Tensor:
+        """All P projections in one launch: [P, bins...] normalised histograms (kde) or densities (hard bins)."""
+        return self.from_sums(self.raw_sums(x, rows), x.shape[0])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._apply_noise(self.batched(x, self.identity_rows(x))[0])
 
 
 class Histogram1D(Histogram):
@@ -94,16 +107,18 @@ class Histogram1D(Histogram):
             return [matrix[self.axis]]
         return [self.direction.to(matrix) @ matrix]
 
-    def batched(self, x: torch.Tensor, rows: List[torch.Tensor]) -> torch.Tensor:
-        """All P projections in one launch: [P, B] normalised histograms (kde) or densities (hard bins)."""
+    def raw_sums(self, x: torch.Tensor, rows: List[torch.Tensor]) -> torch.Tensor:
         V = rows[0].to(torch.float32).contiguous()
         if self.kde:
-            S = ops.ProjKde1dFn.apply(x, V, self.coords, self.bandwidth_value, ops.kde_radius(self.bandwidth_bins))
-            ghat, _ = ops.HistNormDiscFn.apply(S, None, True, 1.0 / x.shape[0], self.resolution_value, 1.0e-10, 0, 0.0, 1.0)
+            return ops.ProjKde1dFn.apply(x, V, self.coords, self.bandwidth_value, ops.kde_radius(self.bandwidth_bins))
+        return ops.proj_hist_counts_1d(x.detach(), V, self.edges).to(torch.float32)
+
+    def from_sums(self, S: torch.Tensor, n_total: int) -> torch.Tensor:
+        if self.kde:
+            ghat, _ = ops.HistNormDiscFn.apply(S, None, True, 1.0 / n_total, self.resolution_value, 1.0e-10, 0, 0.0, 1.0)
             return ghat
-        counts = ops.proj_hist_counts_1d(x.detach(), V, self.edges).to(torch.float32)
         widths = (self.edges[1:] - self.edges[:-1])[None, :]
-        return counts / counts.sum(dim=1, keepdim=True) / widths          # torch.histogram(density=True)
+        return S / S.sum(dim=1, keepdim=True) / widths                    # torch.histogram(density=True)
 
 
 class Histogram2D(Histogram):
@@ -137,20 +152,23 @@ class Histogram2D(Histogram):
     def projection_rows(self, matrix: torch.Tensor) -> List[torch.Tensor]:
         return [matrix[self.axis[0]], matrix[self.axis[1]]]
 
-    def batched(self, x: torch.Tensor, rows: List[torch.Tensor]) -> torch.Tensor:
+    def raw_sums(self, x: torch.Tensor, rows: List[torch.Tensor]) -> torch.Tensor:
         V0 = rows[0].to(torch.float32).contiguous()
         V1 = rows[1].to(torch.float32).contiguous()
         if self.kde:
-            S = ops.ProjKde2dFn.apply(x, V0, V1, self.coords_x, self.coords_y, self.bandwidth_values[0],
-                                      self.bandwidth_values[1], ops.kde_radius(self.bandwidth_bins[0]),
-                                      ops.kde_radius(self.bandwidth_bins[1]))
+            return ops.ProjKde2dFn.apply(x, V0, V1, self.coords_x, self.coords_y, self.bandwidth_values[0],
+                                         self.bandwidth_values[1], ops.kde_radius(self.bandwidth_bins[0]),
+                                         ops.kde_radius(self.bandwidth_bins[1]))
+        return ops.proj_hist_counts_2d(x.detach(), V0, V1, self.edges_x, self.edges_y).to(torch.float32)
+
+    def from_sums(self, S: torch.Tensor, n_total: int) -> torch.Tensor:
+        if self.kde:
             P, Bx, By = S.shape
-            ghat, _ = ops.HistNormDiscFn.apply(S.view(P, Bx * By), None, True, 1.0,
+            ghat, _ = ops.HistNormDiscFn.apply(S.reshape(P, Bx * By), None, True, 1.0,
                                                self.resolution_values[0] * self.resolution_values[1], 1.0e-10, 0, 0.0, 1.0)
             return ghat.view(P, Bx, By)
-        counts = ops.proj_hist_counts_2d(x.detach(), V0, V1, self.edges_x, self.edges_y).to(torch.float32)
         area = (self.edges_x[1:] - self.edges_x[:-1])[:, None] * (self.edges_y[1:] - self.edges_y[:-1])[None, :]
-        return counts / counts.sum(dim=(1, 2), keepdim=True) / area[None]   # np.histogramdd(density=True)
+        return S / S.sum(dim=(1, 2), keepdim=True) / area[None]             # np.histogramdd(density=True)
 
 
 class Projection(Diagnostic):

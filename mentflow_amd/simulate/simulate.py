@@ -78,6 +78,40 @@ def _log_plan(transforms, diagnostics, groups, generic) -> None:
                                                for i, j in generic[:4]]))
 
 
+def raw_sums(x: torch.Tensor, transforms: List[nn.Module], diagnostics: List[List[nn.Module]]):
+    """The measurement set as SUMS over the particles at hand, for data-parallel runs: (pieces, finish) where `pieces` are the
+    raw per-projection sums of every (transform, diagnostic) pair — fused groups and generic pairs alike — and
+    finish(reduced_pieces, n_total) turns the (all-reduced) sums into the reference's predictions[i][j] list
+    (simulate.py:8-33).  Needs diagnostics with a sum form (Histogram1D / Histogram2D); anything else raises, naming it."""
+    groups, generic = group_measurements(transforms, diagnostics)
+    _log_plan(transforms, diagnostics, groups, generic)
+    pieces, recipe = [], []
+    for diagnostic, pre, slots, rows in groups.values():
+        stacked = [torch.stack([r[k] for r in rows]) for k in range(len(rows[0]))]
+        pieces.append(diagnostic.raw_sums(apply_pre(x, pre), stacked))
+        recipe.append((diagnostic, slots))
+    transported: Dict[int, torch.Tensor] = {}
+    for i, j in generic:
+        diagnostic = diagnostics[i][j]
+        if not isinstance(diagnostic, Histogram):
+            raise NotImplementedError(
+                f"data-parallel simulation: {type(diagnostic).__name__} (measurement [{i}][{j}]) has no sum form to reduce over "
+                "the ranks; histogram diagnostics do (Histogram1D / Histogram2D)")
+        if i not in transported:
+            transported[i] = transforms[i](x.clone())
+        pieces.append(diagnostic.raw_sums(transported[i], diagnostic.identity_rows(transported[i])))
+        recipe.append((diagnostic, [(i, j)]))
+
+    def finish(reduced, n_total: int) -> List[List[torch.Tensor]]:
+        predictions: List[List[torch.Tensor]] = [[None] * len(diagnostics[i]) for i in range(len(transforms))]
+        for (diagnostic, slots), S in zip(recipe, reduced):
+            for (i, j), h in zip(slots, diagnostic.from_sums(S, n_total).unbind(0)):
+                predictions[i][j] = diagnostic._apply_noise(h)
+        return predictions
+
+    return pieces, finish
+
+
 def forward(x: torch.Tensor, transforms: List[nn.Module], diagnostics: List[List[nn.Module]]) -> List[List[torch.Tensor]]:
     """simulate.py:8-33: predictions[i][j] = diagnostics[i][j](transforms[i](x))."""
     predictions: List[List[torch.Tensor]] = [[None] * len(diagnostics[i]) for i in range(len(transforms))]

@@ -94,6 +94,90 @@ def test_two_ranks_generic_generator_gradients_are_reduced(emu_library):
     assert torch.equal(out[0][3], out[1][3])
 
 
+def _kick_last_problem(device):
+    """rec_2d/nonlinear optics with the stage order reversed (rotation first, multipole kick LAST): no pair can take the fused
+    projection + KDE launch, MENTFlow.loss runs the reference's generic loop (core.py:113-117) — and a user discrepancy
+    callable on top (the kernels only know kld / mae / mse)."""
+    import numpy as np
+    import mentflow_amd as mf
+    from mentflow_amd.harness import build_problem
+    prob = build_problem(ndim=2, num=3, bins=24, xmax=3.5, seed=21, transforms=2, prior_scale=1.0, device=device,
+                         dist_name="swissroll", optics="2d_linear", meas_samples=4000, penalty_parameter=20.0)
+    tfs = []
+    for k, strength in enumerate(np.linspace(-1.0, 1.0, 3)):
+        rot = mf.simulate.LinearTransform(mf.simulate.rotation_matrix(np.radians(25.0 + 30.0 * k)).type(torch.float32))
+        tfs.append(mf.simulate.CompositeTransform(rot, mf.simulate.MultipoleTransform(order=3, strength=float(strength))).to(device))
+    prob.model.transforms = tfs
+    prob.model._plan = None
+    return prob
+
+
+def _quartic(pred, targ):
+    return torch.sum((pred - targ) ** 4)
+
+
+def _generic_worker(rank, world, port, z, out, user_disc):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from mentflow_amd import _lib, dist as mfdist
+    _lib.use_library(EMU_LIB)
+    dev = mfdist.init_from_env(backend="gloo")
+    prob = _kick_last_problem(dev)
+    if user_disc:
+        prob.model.discrepancy_function = _quartic
+    assert prob.model._fused_plan() is None
+    n = z.shape[0]
+    n_local = mfdist.local_batch(n)
+    start = sum((n // world + (1 if r < n % world else 0)) for r in range(rank))
+    prob.model.generator.inject_z = z[start:start + n_local].clone()
+    L, H, D = prob.model.loss(n)
+    L.backward()
+    g = torch.cat([p.grad.reshape(-1) for p in prob.model.parameters()])
+    out[rank] = (float(L.detach()), float(H.detach()), torch.stack(D).detach(), g)
+    # a diagnostic without a sum form is refused by name, not silently computed on the local shard
+    import mentflow_amd as mf
+    prob.model.diagnostics = [[mf.diagnostics.Projection(axis=0)] for _ in prob.model.transforms]
+    prob.model._plan = None
+    try:
+        prob.model.loss(n)
+        out[f"err{rank}"] = "no error"
+    except NotImplementedError as exc:
+        out[f"err{rank}"] = str(exc)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("user_disc", [False, True])
+def test_two_ranks_generic_loop_equals_one(emu_library, user_disc):
+    """Data-parallel + generic path: transports the fused kernels do not cover (kick after the rotation) run
+    sharded — the ranks all-reduce the raw histogram sums of every measurement in one buffer — and reproduce the
+    single-process (L, H, D) and parameter gradients on the concatenated batch."""
+    from mentflow_amd import _lib
+    _lib.use_library(emu_library)
+    torch.manual_seed(5)
+    n = 257
+    z = torch.randn(n, 2)
+    prob = _kick_last_problem(torch.device("cpu"))
+    if user_disc:
+        prob.model.discrepancy_function = _quartic
+    assert prob.model._fused_plan() is None
+    prob.model.generator.inject_z = z
+    L, H, D = prob.model.loss(n)
+    L.backward()
+    g1 = torch.cat([p.grad.reshape(-1) for p in prob.model.parameters()])
+    assert float(g1.abs().max()) > 0
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_generic_worker, args=(2, _free_port(), z, out, user_disc), nprocs=2, join=True)
+    for r in (0, 1):
+        Lr, Hr, Dr, gr = out[r]
+        assert abs(Lr - float(L.detach())) < 1e-5 + 20 * 1e-6 and abs(Hr - float(H.detach())) < 1e-5
+        torch.testing.assert_close(Dr, torch.stack(D).detach(), rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(gr, g1, rtol=1e-4, atol=1e-6 * float(g1.abs().max()))
+        assert "Projection" in out[f"err{r}"] and "no sum form" in out[f"err{r}"]
+    assert out[0][0] == out[1][0] and torch.equal(out[0][3], out[1][3])
+
+
 def test_local_batch_split():
     from mentflow_amd import dist as mfdist
     assert mfdist.world_size() == 1 and mfdist.rank() == 0 and mfdist.local_batch(17) == 17

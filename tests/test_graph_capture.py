@@ -1,6 +1,7 @@
 """hipGraph capture of the training step (GPU): a replayed step must equal the eager step bit for bit on an injected
 base draw, keep training (fresh particles per replay)."""
 import copy
+import ctypes
 import time
 
 import pytest
@@ -16,9 +17,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("n,fused", [(25_000, "0"), (25_000, "1"), (40_000, "1")])   # two-kernel / fused backward
 def test_graphed_step_equals_eager_and_trains(n, fused, monkeypatch):
-    set_bwd_variant(monkeypatch, fused)
     from mentflow_amd import _lib
-    _lib.use_library(_lib.DEFAULT_PATH)
+    _lib.use_library(_lib.DEFAULT_PATH)                 # FIRST: the variant switch is per-library state
+    set_bwd_variant(monkeypatch, fused)
+    # the two-kernel variant really is the one that runs: it is the only one that needs hand-off scratch
+    order = (ctypes.c_int32 * 6)(*range(6))
+    assert (_lib.get_lib().mf_flow_bwd_scratch_floats(n, 6, 3, order) > 0) == (fused == "0")
     dev = torch.device("cuda", 0)
     prob = build_problem(ndim=6, num=25, bins=64, xmax=4.0, seed=2, transforms=5, prior_scale=1.0, device=dev,
                          dist_name="rings", meas_samples=200_000, penalty_parameter=100.0)
