@@ -99,8 +99,14 @@ class AutoregressiveFlow(GenerativeModel):
         super().__init__()
         if kind not in ("rqs", "affine"):
             raise ValueError(kind)
-        if any(h != packing.HID for h in hidden_features):
-            raise NotImplementedError("the gfx950 flow kernels are built for hidden_units=64 (reference default)")
+        widths = {int(h) for h in hidden_features}
+        if len(widths) != 1 or not 1 <= max(widths) <= packing.HID:
+            raise NotImplementedError(
+                "the gfx950 flow kernels hold a 64-wide conditioner with all its weights in LDS: hidden_units <= 64 (one width for "
+                "every hidden layer; narrower layers run zero-padded at the cost of 64) — 128 units would need 198 KB for the last "
+                "layer alone at d = 6, against 160 KB of LDS per CU")
+        if max(widths) < features - 1:
+            raise NotImplementedError("hidden width smaller than features - 1 is not supported")
         self.features, self.kind, self.bins = int(features), kind, int(bins)
         self.hidden_features = tuple(int(h) for h in hidden_features)
         self.total = 3 * self.bins - 1 if kind == "rqs" else 2

@@ -51,11 +51,22 @@ def slot_of_row(r: int) -> Tuple[int, int]:
 
 
 def hidden_placement(d: int, width: int = HID) -> np.ndarray:
-    """phys[u] = image row of hidden unit u (units sorted by dependency class, two per k-step)."""
+    """phys[u] = image row of hidden unit u (units sorted by dependency class, two per k-step).
+
+    width < 64 (``hidden_units`` below the kernels' width; mentflow/generate/build.py:36-38 takes it from the config): the
+    image keeps its 64 rows and the CLASS SEGMENTS of the 64-wide layout — class c owns the sorted positions
+    [cum64[c-1], cum64[c]) — and the narrower layer fills the first positions of every segment; the remaining rows stay
+    empty (index -1: zero weights, zero bias, relu(0) = 0, gradients never read back).  Every mask-derived k-step bound the
+    kernels compute for the 64-wide structure (make_sparsity in flow_kernels.inc) then still covers exactly the non-zero
+    blocks, so the sparse forward, the fused backward and the activation hand-off run unchanged — at the cost of the 64-wide
+    layer."""
+    if not 1 <= width <= HID:
+        raise NotImplementedError(f"hidden width {width}: the kernels hold a 64-wide conditioner")
     cls = 1 + (np.arange(width) % (d - 1))
-    order = np.lexsort((np.arange(width), cls))          # sorted position j -> unit u
+    cum64 = np.concatenate([[0], class_counts(d, HID)[1:]]) if d > 1 else np.array([0, HID])   # cum64[c] = units of class <= c
     phys = np.empty(width, dtype=np.int64)
-    for j, u in enumerate(order):
+    for u in range(width):
+        j = int(cum64[cls[u] - 1]) + u // (d - 1)          # segment start of the unit's class + its rank inside the class
         s_, half = j >> 1, j & 1
         phys[u] = 32 * (s_ >> 4) + rho(half, s_ & 15)
     return phys
@@ -105,9 +116,12 @@ def layer_image_index(d: int, L: int, kind: str, K: int, masks: Sequence[torch.T
     nblk = d if kind == "rqs" else 1
     g = image_layout(d, L, nblk)
     idx = np.full(g["total"], -1, dtype=np.int64)
-    phys = hidden_placement(d)
+    width = int(masks[0].shape[0])                        # hidden units of the conditioner (<= 64: see hidden_placement)
+    if any(int(m.shape[0]) != width for m in masks[:L]) or int(masks[L].shape[1]) != width:
+        raise NotImplementedError("the hidden layers of a conditioner must share one width")
+    phys = hidden_placement(d, width)
     m0 = masks[0].numpy()
-    for u in range(HID):
+    for u in range(width):
         for j in range(d):
             if m0[u, j]:
                 idx[g["offW0"] + phys[u] * g["S0"] + j] = offsets[0] + u * d + j
@@ -115,10 +129,10 @@ def layer_image_index(d: int, L: int, kind: str, K: int, masks: Sequence[torch.T
     for l in range(1, L):
         ml = masks[l].numpy()
         base = g["offWh"] + (l - 1) * (HID * WS + HID)
-        for u in range(HID):
-            for k in range(HID):
+        for u in range(width):
+            for k in range(width):
                 if ml[u, k]:
-                    idx[base + phys[u] * WS + phys[k]] = offsets[2 * l] + u * HID + k
+                    idx[base + phys[u] * WS + phys[k]] = offsets[2 * l] + u * width + k
             idx[base + HID * WS + phys[u]] = offsets[2 * l + 1] + u
     mo = masks[L].numpy()
     for blk in range(nblk):
@@ -131,9 +145,9 @@ def layer_image_index(d: int, L: int, kind: str, K: int, masks: Sequence[torch.T
                 row = (2 * m + hh) if m < d else -1       # feature m: (shift, scale) = rows 2m, 2m+1
             if row < 0:
                 continue
-            for k in range(HID):
+            for k in range(width):
                 if mo[row, k]:
-                    idx[g["offW3"] + (blk * HID + r) * WS + phys[k]] = offsets[2 * L] + row * HID + k
+                    idx[g["offW3"] + (blk * HID + r) * WS + phys[k]] = offsets[2 * L] + row * width + k
             idx[g["offB3"] + blk * HID + r] = offsets[2 * L + 1] + row
     return idx.astype(np.int32)
 

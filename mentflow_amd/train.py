@@ -60,7 +60,6 @@ class Trainer:
             best_state_dict = copy.deepcopy(model.state_dict())
             gstep = None
             lr_dev = None
-            lr_host = [float(g["lr"]) for g in self.optimizer.param_groups]      # what the scheduler last assigned (for the log)
             if self.graphed:
                 from .graph import GraphedTrainStep
                 if self.lr_on_device:
@@ -78,10 +77,9 @@ class Trainer:
             for iteration in range(iterations):
                 if gstep is not None:
                     if lr_dev is not None:
-                        for k, (g, t) in enumerate(zip(self.optimizer.param_groups, lr_dev)):
-                            if g["lr"] is not t:                                           # the scheduler moved the rate
-                                lr_host[k] = float(g["lr"])
-                                t.fill_(lr_host[k])
+                        for g, t in zip(self.optimizer.param_groups, lr_dev):
+                            if g["lr"] is not t:                                           # the scheduler assigned a new float
+                                t.fill_(float(g["lr"]))
                                 g["lr"] = t
                     elif [g["lr"] for g in self.optimizer.param_groups] != lr_captured:    # float rate: baked into the graph
                         gstep.recapture()
@@ -100,8 +98,9 @@ class Trainer:
                         loss.backward()
                         self.optimizer.step()
                 self._log(dict(epoch=epoch, iteration=iteration, L=L_val, H=H_val, D_norm=D_val, batch_size=batch_size,
-                               learning_rate=(lr_host[0] if lr_dev is not None else float(self.optimizer.param_groups[0]["lr"])),
-                               penalty=model.penalty_parameter,
+                               # (a device-tensor rate is read back here: schedulers such as ReduceLROnPlateau update it IN PLACE,
+                               # so no host copy can follow it; the stream is idle behind the scalar fetch above)
+                               learning_rate=float(self.optimizer.param_groups[0]["lr"]), penalty=model.penalty_parameter,
                                time=time.time() - start_time))
                 if L_val < best_loss:                                                             # train.py:197-199
                     best_loss = L_val
@@ -121,15 +120,11 @@ class Trainer:
                         model.train()
                 if self.lr_scheduler is not None:
                     self.lr_scheduler.step(L_val)                                                 # train.py:214
-                    if lr_dev is not None:      # keep the host copy current without reading the device tensor back
-                        for k, g in enumerate(self.optimizer.param_groups):
-                            if not torch.is_tensor(g["lr"]):
-                                lr_host[k] = float(g["lr"])
             if lr_dev is not None:
                 # hand the optimizer back with plain float rates: state_dict() / checkpoints and a later non-capturable use must
-                # not find device tensors in param_groups
-                for k, g in enumerate(self.optimizer.param_groups):
-                    g["lr"] = float(g["lr"]) if not torch.is_tensor(g["lr"]) else lr_host[k]
+                # not find device tensors in param_groups (one read-back per epoch)
+                for g in self.optimizer.param_groups:
+                    g["lr"] = float(g["lr"])
             return best_state_dict
 
         converged, final_epoch = False, False

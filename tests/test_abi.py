@@ -74,5 +74,5 @@ def test_unsupported_pieces_raise():
     nn_gen = mf.generate.build_generator("nn", input_features=2, output_features=2, hidden_layers=3, hidden_units=64)
     assert nn_gen.log_prob(None) is None and nn_gen.sample_and_log_prob(5)[0].shape == (5, 2)
     with pytest.raises(NotImplementedError):
-        mf.generate.build_generator("nsf", input_features=2, output_features=2, hidden_layers=3, hidden_units=50,
+        mf.generate.build_generator("nsf", input_features=2, output_features=2, hidden_layers=3, hidden_units=96,
                                     transforms=1)
