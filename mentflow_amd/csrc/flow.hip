@@ -22,11 +22,11 @@ static int flow_grid(int64_t n, int waves = FLOW_WAVES) {
 }
 
 static int no_rqs_instance(int bins, int hidden_layers) {
-    return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: 2 <= bins <= 21, hidden_layers in {2,3})", bins,
+    return fail("no RQS kernel instance for bins=%d hidden_layers=%d (built: 2 <= bins <= 21, hidden_layers in {1,2,3,4})", bins,
                 hidden_layers);
 }
 static int no_affine_instance(int hidden_layers) {
-    return fail("no affine kernel instance for hidden_layers=%d (built: 2, 3)", hidden_layers);
+    return fail("no affine kernel instance for hidden_layers=%d (built: 1 .. 4)", hidden_layers);
 }
 
 }  // namespace mf

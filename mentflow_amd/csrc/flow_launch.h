@@ -14,8 +14,11 @@ namespace mf {
 
 // Built spline instances: bins 20 (the reference's value, experiments/setup.py:119-121) and 8 (zuko's default) at compile
 // time; every other 2 <= bins <= 21 through the run-time instance (RQS_ANY: slots laid out for 21 bins, slower).
-#define MF_RQS_CASES(X) X(20, 3) X(20, 2) X(8, 3) X(8, 2) X(RQS_ANY, 3) X(RQS_ANY, 2)
-#define MF_AFFINE_CASES(X) X(3) X(2)
+// hidden_layers: 3 (the reference's default, config/gen/flow.yaml:2) and 2 are the tuned instances; 1 and 4 are built as well
+// (mentflow/generate/build.py:36-38 takes the depth from the config) — 4 layers fit the fused backward's LDS budget only for small d
+// and otherwise take the two-kernel backward, neither has a hand-off level.
+#define MF_RQS_CASES(X) X(20, 3) X(20, 2) X(8, 3) X(8, 2) X(RQS_ANY, 3) X(RQS_ANY, 2) X(20, 4) X(20, 1) X(8, 4) X(8, 1) X(RQS_ANY, 4) X(RQS_ANY, 1)
+#define MF_AFFINE_CASES(X) X(3) X(2) X(4) X(1)
 inline bool rqs_case_matches(int KK, int bins) {
     return KK == RQS_ANY ? (bins != 20 && bins != 8 && bins >= 2 && bins <= RQS_KMAX) : bins == KK;
 }

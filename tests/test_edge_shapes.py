@@ -122,7 +122,7 @@ def test_unsupported_shapes_fail_loudly(backend):
                                       transforms=1, bins=22).to(backend)
     with pytest.raises(NotImplementedError, match="2 <= bins <= 21"):
         gen.sample_and_log_prob(8, z=torch.randn(8, 2).to(backend))
-    gen = mf.generate.build_generator("nsf", input_features=2, output_features=2, hidden_layers=4, hidden_units=64,
+    gen = mf.generate.build_generator("nsf", input_features=2, output_features=2, hidden_layers=5, hidden_units=64,
                                       transforms=1, bins=8).to(backend)
     with pytest.raises(RuntimeError, match="no RQS kernel instance"):
         gen.sample_and_log_prob(8, z=torch.randn(8, 2).to(backend))
