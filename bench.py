@@ -45,7 +45,9 @@ NUM_CU = 256
 # (profiles/r04_kde_bwd_instruction_mix.txt): (full-rate VALU, transcendental, LDS).  A wave64 instruction holds its SIMD-32 for
 # 2 cycles, a transcendental one for 8 (/opt/skills/guides/MI355X_MICROARCH.md, per-instruction cycle constants); the LDS reads
 # (2 cycles per ds_read_b32 on the CU's one LDS) stay under the VALU time of the four SIMDs and are reported, not booked.
-KDE_BWD_MIX = {"kde1d_bwd": (168, 9, 20), "kde2d_bwd": (500, 18, 87)}
+# 1-D: the INTERIOR path (whole window inside the grid: all but the outermost 4 bins) = 19 preamble + 59 window + 8 gradient-row
+# instructions; the general (edge) path issues 170.
+KDE_BWD_MIX = {"kde1d_bwd": (86, 9, 12), "kde2d_bwd": (500, 18, 87)}
 VALU_CYCLES, TRANS_CYCLES, SIMDS = 2, 8, 4 * NUM_CU
 
 WORKLOADS = {

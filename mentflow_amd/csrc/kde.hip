@@ -264,7 +264,20 @@ __global__ __launch_bounds__(BLOCK) void proj_kde1d_bwd_kernel(
             const float u = project8(xv, vq);
             const int kc = centre_bin(u, c0, inv_delta, B, R);
             float du = 0.0f;
-            if (RT > 0) {
+            if (RT > 0 && kc >= RT && kc < B - RT) {
+                // INTERIOR particle (all but the outermost RT bins of a distribution): the whole window lies inside the grid —
+                // no clamps, no masks, and the 2 RT + 1 bin centres / gS values are consecutive LDS words read at immediate
+                // offsets of ONE address each.  The kernel is bound by vector issue (168 full-rate instructions per particle
+                // and projection in the general path, profiles/r04_kde_bwd_instruction_mix.txt): this path issues a third
+                // fewer.  Same residuals from the table of bin centres, same terms, summed in the same order.
+                const float* cp = cl + (kc - RT);
+                const float* gp = img + q * B + (kc - RT);
+#pragma unroll
+                for (int j = 0; j <= 2 * RT; ++j) {
+                    const float r = (u - cp[j]) * inv_sigma;
+                    du += gp[j] * gauss_weight(r) * (-r * inv_sigma);
+                }
+            } else if (RT > 0) {
                 // window bins outside [0, B) read a clamped bin and are masked: no divergent branch in the unrolled loop
                 // (NaN / inf rows: every bin is out of range, every term is masked, the gradient row is exactly 0)
                 // residuals from the table of bin centres, exactly as the reference forms them (the backward is VALU /
