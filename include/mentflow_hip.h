@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 4
+#define MF_ABI_VERSION 5
 #define MF_ENTROPY_SCRATCH_DOUBLES 2048
 
 int mf_abi_version(void);
@@ -135,6 +135,31 @@ int mf_flow_affine_layer_bwd(const float* image, int d, int hidden_layers, const
                              int accumulate, float* scratch, int64_t scratch_floats, void* stream);
 int mf_flow_affine_layer_inv(const float* image, int d, int hidden_layers, const int32_t* order, const float* y,
                              int64_t n, float* x, void* stream);
+
+/* Wide conditioners (ABI 5): the same layers for hidden widths up to 128 units and / or up to 16 features — shapes whose weights
+ * do not fit the 160 KiB of LDS the 64-wide entry points above keep them in (mentflow/generate/build.py:36-38 takes hidden_units
+ * and hidden_layers from the config; zuko accepts any).  One family for both transforms: bins = 0 selects the affine (MAF)
+ * transform, 2 <= bins <= 21 the rational-quadratic spline.  Differences to the entry points above:
+ *   - `image` (mf_flow_wide_image_floats(hidden_layers, nblk) floats, nblk = d for the spline, 1 for affine) holds every weight
+ *     matrix twice, as forward and as transposed 32 x 32 MFMA FRAGMENT blocks, and stays in global memory (L2-resident); its layout
+ *     is documented in mentflow_amd/csrc/flow_wide.hip and produced by mentflow_amd/generate/packing.py (wide_image_index);
+ *   - gslab rows have mf_flow_wide_grad_floats(hidden_layers, nblk) floats in NATURAL order (padded physical rows / columns);
+ *     pass that number as `image_floats` to mf_flow_grad_reduce;
+ *   - `hidden` = hidden units (1 .. 128; all hidden layers share it), hidden_layers 1 .. 4, d 1 .. 16 (mf_flow_wide_limits);
+ *   - the backward is always the two-kernel form: `scratch` needs mf_flow_wide_bwd_scratch_floats floats.                        */
+int mf_flow_wide_limits(int* max_features, int* max_hidden, int* max_hidden_layers);
+int64_t mf_flow_wide_image_floats(int hidden_layers, int nblk);
+int64_t mf_flow_wide_grad_floats(int hidden_layers, int nblk);
+int mf_flow_wide_layer_fwd(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
+                           const float* x, int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp,
+                           void* stream);
+int64_t mf_flow_wide_bwd_scratch_floats(int64_t n, int d, int hidden_layers, int bins);
+int mf_flow_wide_bwd_slab_rows(int64_t n);
+int mf_flow_wide_layer_bwd(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
+                           const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gslab,
+                           int slab_rows, int accumulate, float* scratch, int64_t scratch_floats, void* stream);
+int mf_flow_wide_layer_inv(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
+                           const float* y, int64_t n, float* x, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused linear projection + 1-D Gaussian-KDE histogram over P projections.

@@ -52,6 +52,15 @@ PROTOTYPES = {
     "mf_flow_affine_bwd_slab_rows": (_i32, [_i64]),
     "mf_flow_affine_layer_bwd": (_i32, [_ptr, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr, _i64,
                                         _ptr]),
+    "mf_flow_wide_limits": (_i32, [_ptr, _ptr, _ptr]),
+    "mf_flow_wide_image_floats": (_i64, [_i32, _i32]),
+    "mf_flow_wide_grad_floats": (_i64, [_i32, _i32]),
+    "mf_flow_wide_layer_fwd": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32, _ptr]),
+    "mf_flow_wide_bwd_scratch_floats": (_i64, [_i64, _i32, _i32, _i32]),
+    "mf_flow_wide_bwd_slab_rows": (_i32, [_i64]),
+    "mf_flow_wide_layer_bwd": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr,
+                                      _i64, _ptr]),
+    "mf_flow_wide_layer_inv": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr]),
     "mf_proj_kde_ws_bytes": (_i64, [_i32, _i32]),
     "mf_proj_kde1d_fwd": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _i32, _f32, _i32, _ptr, _ptr, _ptr]),
     "mf_proj_kde1d_bwd": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _i32, _f32, _i32, _ptr, _ptr, _i32, _ptr]),
@@ -91,7 +100,7 @@ def use_library(path: str) -> None:
     """Load a specific build of the C-ABI library (tests only)."""
     global _lib, _device_type
     lib = _bind(C.CDLL(path))
-    if lib.mf_abi_version() != 4:
+    if lib.mf_abi_version() != 5:
         raise LibraryError(f"ABI version mismatch in {path}")
     _lib = lib
     _device_type = "cpu" if lib.mf_is_emulation() else "cuda"

@@ -100,13 +100,19 @@ class AutoregressiveFlow(GenerativeModel):
         if kind not in ("rqs", "affine"):
             raise ValueError(kind)
         widths = {int(h) for h in hidden_features}
-        if len(widths) != 1 or not 1 <= max(widths) <= packing.HID:
+        if len(widths) != 1 or not 1 <= max(widths) <= packing.WIDE_HP:
             raise NotImplementedError(
-                "the gfx950 flow kernels hold a 64-wide conditioner with all its weights in LDS: hidden_units <= 64 (one width for "
-                "every hidden layer; narrower layers run zero-padded at the cost of 64) — 128 units would need 198 KB for the last "
-                "layer alone at d = 6, against 160 KB of LDS per CU")
+                f"the gfx950 flow kernels take one width for every hidden layer and hidden_units <= {packing.WIDE_HP} "
+                f"(got {tuple(hidden_features)})")
+        if features > packing.WIDE_DMAX:
+            raise NotImplementedError(f"the gfx950 flow kernels take up to {packing.WIDE_DMAX} features (got {features})")
         if max(widths) < features - 1:
             raise NotImplementedError("hidden width smaller than features - 1 is not supported")
+        # Two kernel families behind one module.  Up to 64 hidden units and 7 features: the tuned kernels that keep the layer's
+        # weights in LDS (narrower layers ride zero-padded in the 64-wide image).  Beyond (hidden_units 65 .. 128 or 8 .. 16
+        # features; mentflow/generate/build.py:36-38 takes both from the config): the wide family, weights in global memory as MFMA
+        # fragment blocks (mentflow_amd/csrc/flow_wide.hip) — the 128-wide last layer alone is 198 KB at d = 6, against 160 KB of LDS.
+        self.wide = max(widths) > packing.HID or features > 7
         self.features, self.kind, self.bins = int(features), kind, int(bins)
         self.hidden_features = tuple(int(h) for h in hidden_features)
         self.total = 3 * self.bins - 1 if kind == "rqs" else 2
@@ -223,11 +229,24 @@ class AutoregressiveFlow(GenerativeModel):
             if deriv_slot < 0:
                 raise NotImplementedError(f"bins={self.bins}: the spline kernels take 2 <= bins <= 21 (32 slots per lane half)")
         idx = []
+        if self.wide:
+            nblk = d if self.kind == "rqs" else 1
+            grad_floats = packing.wide_grad_layout(L, nblk)["total"]
+            grad_index = np.full(numel, -1, dtype=np.int64)
+            for t, layer in enumerate(self.layers):
+                masks = [lin.mask.cpu() for lin in layer.linears()]
+                img, gparam, gpos = packing.wide_image_index(d, L, self.kind, self.bins, masks,
+                                                             offsets[t * per_layer:(t + 1) * per_layer], deriv_slot)
+                idx.append(img)
+                grad_index[gparam] = t * grad_floats + gpos
+            self._grad_floats = grad_floats
+            return np.concatenate(idx), grad_index.astype(np.int32), idx[0].size
         for t, layer in enumerate(self.layers):
             masks = [lin.mask.cpu() for lin in layer.linears()]
             idx.append(packing.layer_image_index(d, L, self.kind, self.bins, masks,
                                                  offsets[t * per_layer:(t + 1) * per_layer], deriv_slot))
         image_index = np.concatenate(idx)
+        self._grad_floats = idx[0].size
         return image_index, packing.invert_index(image_index, numel), idx[0].size
 
     def spec(self) -> ops.FlowSpec:
@@ -235,14 +254,21 @@ class AutoregressiveFlow(GenerativeModel):
         if self._spec is None or self._spec_device != dev:
             image_index, grad_index, image_floats = self.build_index_maps()
             lib = get_lib()
-            expect = (lib.mf_flow_image_floats(self.features, len(self.hidden_features)) if self.kind == "rqs"
-                      else lib.mf_flow_affine_image_floats(self.features, len(self.hidden_features)))
-            if expect != image_floats:
-                raise RuntimeError(f"image layout mismatch: host {image_floats} vs library {expect}")
-            self._spec = ops.FlowSpec(self.features, len(self.hidden_features), len(self.layers), self.kind, self.bins,
+            L = len(self.hidden_features)
+            if self.wide:
+                nblk = self.features if self.kind == "rqs" else 1
+                expect, expect_g = lib.mf_flow_wide_image_floats(L, nblk), lib.mf_flow_wide_grad_floats(L, nblk)
+            else:
+                expect = (lib.mf_flow_image_floats(self.features, L) if self.kind == "rqs"
+                          else lib.mf_flow_affine_image_floats(self.features, L))
+                expect_g = expect
+            if expect != image_floats or expect_g != self._grad_floats:
+                raise RuntimeError(f"image layout mismatch: host {image_floats} / {self._grad_floats} vs library {expect} / {expect_g}")
+            self._spec = ops.FlowSpec(self.features, L, len(self.layers), self.kind, self.bins,
                                       image_floats, torch.from_numpy(image_index).to(dev),
                                       torch.from_numpy(grad_index).to(dev),
-                                      [layer.order.cpu().tolist() for layer in self.layers])
+                                      [layer.order.cpu().tolist() for layer in self.layers],
+                                      wide=self.wide, hidden=self.hidden_features[0], grad_floats=self._grad_floats)
             self._spec_device = dev
         return self._spec
 

@@ -158,3 +158,167 @@ def invert_index(image_index: np.ndarray, numel: int) -> np.ndarray:
     pos = np.nonzero(image_index >= 0)[0]
     inv[image_index[pos]] = pos
     return inv.astype(np.int32)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Wide conditioners (hidden_units 65 .. 128 and / or 8 .. 16 features): mentflow_amd/csrc/flow_wide.hip.  The weights stay
+# in global memory as 32 x 32 MFMA FRAGMENT blocks (forward and transposed copies); the gradient image is a separate,
+# natural-order layout.  Hidden units are again placed sorted by dependency class, over the actual width.
+WIDE_HT = 4
+WIDE_HP = 32 * WIDE_HT
+WIDE_DMAX = 16
+WIDE_FB = 1024
+
+
+def wide_placement(d: int, width: int) -> np.ndarray:
+    """phys[u] = physical row (0 .. 127) of hidden unit u: units sorted by dependency class c_u = 1 + (u mod (d-1)), sorted
+    position j in MFMA row 32*((j>>1)>>4) + rowmap((j>>1)&15, j&1) — so that sorted positions 32t .. 32t+31 are hidden tile t and
+    the autoregressive masks are block-triangular over tiles (make_wide_sp in flow_wide.hip computes the same counts)."""
+    if not 1 <= width <= WIDE_HP:
+        raise NotImplementedError(f"hidden width {width}: the wide kernels hold up to {WIDE_HP} units")
+    if d > 1:
+        cls = 1 + (np.arange(width) % (d - 1))
+        cum = np.array([(cls <= c).sum() for c in range(d)], dtype=np.int64)
+        j = cum[cls - 1] + np.arange(width) // (d - 1)
+    else:
+        j = np.arange(width)
+    s_, half = j >> 1, j & 1
+    return (32 * (s_ >> 4) + (s_ & 3) + 8 * ((s_ & 15) >> 2) + 4 * half).astype(np.int64)
+
+
+def wide_layout(L: int, nblk: int) -> dict:
+    g = {"offW0F": 0}
+    g["offB0"] = WIDE_HT * 512
+    g["offW0T"] = g["offB0"] + WIDE_HT * 32
+    g["offH"] = g["offW0T"] + WIDE_HT * WIDE_FB
+    g["strideH"] = 2 * WIDE_HT * WIDE_HT * WIDE_FB + WIDE_HT * 32
+    g["off3"] = g["offH"] + (L - 1) * g["strideH"]
+    g["stride3"] = 2 * WIDE_HT * WIDE_FB + WIDE_HT * 2 * WIDE_FB + 64
+    g["total"] = g["off3"] + nblk * g["stride3"]
+    return g
+
+
+def wide_grad_layout(L: int, nblk: int) -> dict:
+    g = {"offW0": 0, "offB0": WIDE_HP * WIDE_DMAX}
+    g["offH"] = g["offB0"] + WIDE_HP
+    g["strideH"] = WIDE_HP * WIDE_HP + WIDE_HP
+    g["off3"] = g["offH"] + (L - 1) * g["strideH"]
+    g["stride3"] = 64 * WIDE_HP + 64
+    g["total"] = g["off3"] + nblk * g["stride3"]
+    return g
+
+
+_LANE = np.arange(64)
+_COL, _HH = _LANE & 31, _LANE >> 5
+_G4, _J4 = np.meshgrid(np.arange(4), np.arange(4), indexing="ij")              # [g, j]
+_KROW = ((_G4 * 4 + _J4) & 3)[:, None, :] + 8 * ((_G4 * 4 + _J4) >> 2)[:, None, :] + 4 * _HH[None, :, None]   # rowmap(4g+j, hh): [g, lane, j]
+_COLB = np.broadcast_to(_COL[None, :, None], (4, 64, 4))
+
+
+def _frag_f(nat: np.ndarray, rt: int, it: int) -> np.ndarray:
+    """forward fragment block (rt, it): (g, lane, j) -> nat[32 rt + col][32 it + rowmap(4g + j, hh)]"""
+    return nat[32 * rt + _COLB, 32 * it + _KROW].reshape(-1)
+
+
+def _frag_t(nat: np.ndarray, it: int, kt: int) -> np.ndarray:
+    """transposed fragment block (it, kt): (g, lane, j) -> nat[32 kt + rowmap(4g + j, hh)][32 it + col]"""
+    return nat[32 * kt + _KROW, 32 * it + _COLB].reshape(-1)
+
+
+def _frag_bias(nb: np.ndarray, tiles: int) -> np.ndarray:
+    """(rt, hh, r) -> nb[32 rt + rowmap(r, hh)]"""
+    r = np.arange(16)
+    rows = np.stack([32 * rt + (r & 3) + 8 * (r >> 2) + 4 * hh for rt in range(tiles) for hh in range(2)])
+    return nb[rows].reshape(-1)
+
+
+def wide_image_index(d: int, L: int, kind: str, K: int, masks: Sequence[torch.Tensor], offsets: Sequence[int],
+                     deriv_slot: int = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(image_index int32 [wide image floats] -> flat parameter index or -1,
+        grad_param int64 [m], grad_pos int64 [m]: parameter grad_param[i] receives position grad_pos[i] of the gradient image).
+
+    Arguments as layer_image_index.  Every unmasked parameter appears in the weight image twice (forward and transposed
+    fragments; biases once) and in the gradient image once."""
+    if d > WIDE_DMAX:
+        raise NotImplementedError(f"the wide flow kernels take up to {WIDE_DMAX} features (got {d})")
+    total_per_feature = 3 * K - 1 if kind == "rqs" else 2
+    nblk = d if kind == "rqs" else 1
+    width = int(masks[0].shape[0])
+    if any(int(m.shape[0]) != width for m in masks[:L]) or int(masks[L].shape[1]) != width:
+        raise NotImplementedError("the hidden layers of a conditioner must share one width")
+    phys = wide_placement(d, width)
+    g, gg = wide_layout(L, nblk), wide_grad_layout(L, nblk)
+    img = np.full(g["total"], -1, dtype=np.int64)
+    gparam: List[np.ndarray] = []
+    gpos: List[np.ndarray] = []
+
+    def grad_entries(nat: np.ndarray, off: int, stride: int) -> None:
+        r, c = np.nonzero(nat >= 0)
+        gparam.append(nat[r, c])
+        gpos.append(off + r * stride + c)
+
+    def grad_bias(nb: np.ndarray, off: int) -> None:
+        r = np.nonzero(nb >= 0)[0]
+        gparam.append(nb[r])
+        gpos.append(off + r)
+
+    # input layer
+    nat0 = np.full((WIDE_HP, 32), -1, dtype=np.int64)             # 32 columns: the transposed fragments index col = 0 .. 31
+    m0 = masks[0].numpy().astype(bool)
+    u, j = np.nonzero(m0)
+    nat0[phys[u], j] = offsets[0] + u * d + j
+    nb0 = np.full(WIDE_HP, -1, dtype=np.int64)
+    nb0[phys] = offsets[1] + np.arange(width)
+    for rt in range(WIDE_HT):
+        for gx in range(2):
+            jj = np.arange(4)
+            colsx = 2 * (4 * gx + jj)[None, :] + _HH[:, None]                      # [lane, j] -> input feature 2 (4 gx + j) + hh
+            img[g["offW0F"] + (rt * 2 + gx) * 256:][:256] = nat0[32 * rt + _COL[:, None], colsx].reshape(-1)
+        img[g["offW0T"] + rt * WIDE_FB:][:WIDE_FB] = _frag_t(nat0, 0, rt)
+    img[g["offB0"]:][:WIDE_HT * 32] = _frag_bias(nb0, WIDE_HT)
+    grad_entries(nat0[:, :WIDE_DMAX], gg["offW0"], WIDE_DMAX)
+    grad_bias(nb0, gg["offB0"])
+    # hidden layers
+    for l in range(1, L):
+        ml = masks[l].numpy().astype(bool)
+        nat = np.full((WIDE_HP, WIDE_HP), -1, dtype=np.int64)
+        u, k = np.nonzero(ml)
+        nat[phys[u], phys[k]] = offsets[2 * l] + u * width + k
+        nb = np.full(WIDE_HP, -1, dtype=np.int64)
+        nb[phys] = offsets[2 * l + 1] + np.arange(width)
+        base = g["offH"] + (l - 1) * g["strideH"]
+        for a in range(WIDE_HT):
+            for b in range(WIDE_HT):
+                img[base + (a * WIDE_HT + b) * WIDE_FB:][:WIDE_FB] = _frag_f(nat, a, b)
+                img[base + WIDE_HT * WIDE_HT * WIDE_FB + (a * WIDE_HT + b) * WIDE_FB:][:WIDE_FB] = _frag_t(nat, a, b)
+        img[base + 2 * WIDE_HT * WIDE_HT * WIDE_FB:][:WIDE_HT * 32] = _frag_bias(nb, WIDE_HT)
+        gbase = gg["offH"] + (l - 1) * gg["strideH"]
+        grad_entries(nat, gbase, WIDE_HP)
+        grad_bias(nb, gbase + WIDE_HP * WIDE_HP)
+    # output blocks
+    mo = masks[L].numpy().astype(bool)
+    for blk in range(nblk):
+        nat = np.full((64, WIDE_HP), -1, dtype=np.int64)
+        nb = np.full(64, -1, dtype=np.int64)
+        for r in range(64):
+            hh, m = slot_of_row(r)
+            if kind == "rqs":
+                t = rqs_logical_param(hh, m, K, deriv_slot)
+                row = blk * total_per_feature + t if t >= 0 else -1
+            else:
+                row = (2 * m + hh) if m < d else -1
+            if row < 0:
+                continue
+            k = np.nonzero(mo[row])[0]
+            nat[r, phys[k]] = offsets[2 * L] + row * width + k
+            nb[r] = offsets[2 * L + 1] + row
+        base = g["off3"] + blk * g["stride3"]
+        for rt in range(2):
+            for it in range(WIDE_HT):
+                img[base + (rt * WIDE_HT + it) * WIDE_FB:][:WIDE_FB] = _frag_f(nat, rt, it)
+                img[base + 2 * WIDE_HT * WIDE_FB + (it * 2 + rt) * WIDE_FB:][:WIDE_FB] = _frag_t(nat, it, rt)
+        img[base + 4 * WIDE_HT * WIDE_FB:][:64] = _frag_bias(nb, 2)
+        gbase = gg["off3"] + blk * gg["stride3"]
+        grad_entries(nat, gbase, WIDE_HP)
+        grad_bias(nb, gbase + 64 * WIDE_HP)
+    return img.astype(np.int32), np.concatenate(gparam), np.concatenate(gpos)

@@ -36,8 +36,13 @@ class FlowSpec:
     """Static description of a packed flow (shared by every call): geometry + device index maps."""
 
     def __init__(self, d: int, hidden_layers: int, transforms: int, kind: str, bins: int, image_floats: int,
-                 image_index: torch.Tensor, grad_index: torch.Tensor, orders):
+                 image_index: torch.Tensor, grad_index: torch.Tensor, orders, wide: bool = False, hidden: int = 64,
+                 grad_floats: Optional[int] = None):
         self.d, self.L, self.T, self.kind, self.bins = d, hidden_layers, transforms, kind, bins
+        # wide = the mf_flow_wide_* family (hidden_units 65 .. 128 and / or 8 .. 16 features: weights in global memory as MFMA
+        # fragments, two-kernel backward, gradient slabs of `grad_floats` floats in natural order)
+        self.wide, self.hidden = bool(wide), int(hidden)
+        self.grad_floats = int(image_floats if grad_floats is None else grad_floats)
         # per layer: host int32 array of the autoregressive order (lets the kernels skip masked-out MFMA k-steps)
         self.orders = [(C.c_int32 * d)(*[int(v) for v in o]) for o in orders]
         self.sparse = True
@@ -54,7 +59,7 @@ class FlowSpec:
         self._act_supported: Optional[int] = None
 
     def resolve_act_level(self, n: int, device: torch.device) -> int:
-        if self.kind != "rqs" or not self.sparse or n <= 0:
+        if self.kind != "rqs" or not self.sparse or self.wide or n <= 0:
             return 0
         lib = _lib.get_lib()
         supported = min(lib.mf_flow_rqs_act_level(self.d, self.L, self.bins, o) for o in self.orders)
@@ -72,7 +77,10 @@ def _layer_fwd(spec: FlowSpec, t: int, image: torch.Tensor, x: torch.Tensor, y: 
                act_level: int = 0) -> None:
     n = x.shape[0]
     order = spec.orders[t] if spec.sparse else None
-    if act_level > 0:
+    if spec.wide:
+        call("mf_flow_wide_layer_fwd", ptr(image), spec.d, spec.hidden, spec.L, spec.bins if spec.kind == "rqs" else 0, order,
+             ptr(x), n, ptr(y), ptr(logp_in), ptr(logp_out), int(init), stream_ptr(x))
+    elif act_level > 0:
         call("mf_flow_rqs_layer_fwd_save", ptr(image), spec.d, spec.L, spec.bins, order, ptr(x), n, ptr(y), ptr(logp_in),
              ptr(logp_out), int(init), ptr(act), act.numel(), int(act_level), stream_ptr(x))
     elif spec.kind == "rqs":
@@ -88,7 +96,11 @@ def _layer_bwd(spec: FlowSpec, t: int, image, x, gy, glogp, gx, gslab, accumulat
     n = x.shape[0]
     order = spec.orders[t] if spec.sparse else None
     rows = gslab.shape[0]
-    if act_level > 0:
+    if spec.wide:
+        call("mf_flow_wide_layer_bwd", ptr(image), spec.d, spec.hidden, spec.L, spec.bins if spec.kind == "rqs" else 0, order,
+             ptr(x), n, ptr(gy), ptr(glogp), ptr(gx), ptr(gslab), rows, int(accumulate), ptr(scratch), scratch.numel(),
+             stream_ptr(x))
+    elif act_level > 0:
         call("mf_flow_rqs_layer_bwd_saved", ptr(image), spec.d, spec.L, spec.bins, order, ptr(x), n, ptr(gy), ptr(glogp),
              ptr(gx), ptr(gslab), rows, int(accumulate), ptr(act), act.numel(), int(act_level), stream_ptr(x))
     elif spec.kind == "rqs":
@@ -105,7 +117,13 @@ def _bwd_plan(spec: FlowSpec, n: int):
     chunk of a pass must write the same number of slab rows (each workgroup accumulates into its own row), so a ragged
     last chunk is only allowed when it does."""
     lib = _lib.get_lib()
-    if spec.kind == "rqs":
+    if spec.wide:
+        def need(m):
+            return lib.mf_flow_wide_bwd_scratch_floats(m, spec.d, spec.L, spec.bins if spec.kind == "rqs" else 0)
+
+        def rows(m):
+            return lib.mf_flow_wide_bwd_slab_rows(m)
+    elif spec.kind == "rqs":
         orders = spec.orders if spec.sparse else [None]
 
         def need(m):
@@ -196,7 +214,7 @@ class FlowSampleFn(torch.autograd.Function):
             groups.setdefault(rows_of(b - a), []).append((a, b))
         gflat = None
         g = gx
-        slabs = {r: torch.empty(spec.T, r, spec.image_floats, dtype=_F32, device=dev) for r in groups}
+        slabs = {r: torch.empty(spec.T, r, spec.grad_floats, dtype=_F32, device=dev) for r in groups}
         need_gz = ctx.needs_input_grad[0]             # dL/dz: the reference's transform is differentiable in the base draw
         for t in reversed(range(spec.T)):
             gprev = torch.empty_like(g) if (t > 0 or need_gz) else None
@@ -207,7 +225,7 @@ class FlowSampleFn(torch.autograd.Function):
             g = gprev
         for r, slab in slabs.items():
             part = torch.empty(spec.grad_index.numel(), dtype=_F32, device=dev)
-            call("mf_flow_grad_reduce", ptr(slab), spec.T, r, spec.image_floats, ptr(spec.grad_index), ptr(part),
+            call("mf_flow_grad_reduce", ptr(slab), spec.T, r, spec.grad_floats, ptr(spec.grad_index), ptr(part),
                  part.numel(), stream_ptr(part))
             gflat = part if gflat is None else gflat + part
         # g is now dL/dz through x and the log-det; log_prob also holds the base density logN(z) = -|z|^2/2 - const
@@ -241,7 +259,10 @@ def flow_layers_inverse(x: torch.Tensor, flat: torch.Tensor, spec: FlowSpec) -> 
     zs = [x]
     for t in reversed(range(spec.T)):
         out = torch.empty_like(x)
-        if spec.kind == "rqs":
+        if spec.wide:
+            call("mf_flow_wide_layer_inv", ptr(images[t]), spec.d, spec.hidden, spec.L, spec.bins if spec.kind == "rqs" else 0,
+                 spec.orders[t], ptr(zs[-1]), x.shape[0], ptr(out), stream_ptr(x))
+        elif spec.kind == "rqs":
             call("mf_flow_rqs_layer_inv", ptr(images[t]), spec.d, spec.L, spec.bins, spec.orders[t], ptr(zs[-1]),
                  x.shape[0], ptr(out), stream_ptr(x))
         else:

@@ -32,7 +32,7 @@ def test_header_symbols_are_exported_by_the_gfx950_library(hip_library):
         assert hasattr(lib, name), f"{name} declared in include/mentflow_hip.h but not exported"
     lib.mf_abi_version.restype = ctypes.c_int
     lib.mf_is_emulation.restype = ctypes.c_int
-    assert lib.mf_abi_version() == 4
+    assert lib.mf_abi_version() == 5
     assert lib.mf_is_emulation() == 0                 # the product library is the real thing
     # the code object really is gfx950
     blob = open(hip_library, "rb").read()
@@ -74,5 +74,5 @@ def test_unsupported_pieces_raise():
     nn_gen = mf.generate.build_generator("nn", input_features=2, output_features=2, hidden_layers=3, hidden_units=64)
     assert nn_gen.log_prob(None) is None and nn_gen.sample_and_log_prob(5)[0].shape == (5, 2)
     with pytest.raises(NotImplementedError):
-        mf.generate.build_generator("nsf", input_features=2, output_features=2, hidden_layers=3, hidden_units=96,
+        mf.generate.build_generator("nsf", input_features=2, output_features=2, hidden_layers=3, hidden_units=196,
                                     transforms=1)

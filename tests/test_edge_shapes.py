@@ -111,12 +111,12 @@ def test_flow_every_compiled_instance(backend, d, bins, L):
 
 
 def test_unsupported_shapes_fail_loudly(backend):
-    """hidden_units above 64 is refused when the generator is built (narrower conditioners run zero-padded:
-    test_narrow_conditioner_matches_oracle); bins beyond the 32 slots of a lane half and
+    """hidden_units above 128 and mixed widths are refused when the generator is built (65 .. 128 run the wide family:
+    tests/test_flow_wide.py; narrower conditioners run zero-padded: test_narrow_conditioner_matches_oracle); bins beyond the 32 slots of a lane half and
     hidden_layers without a compiled instance are refused with a message that names what exists — nothing falls back
     silently."""
     with pytest.raises(NotImplementedError):
-        mf.generate.build_generator("nsf", input_features=2, output_features=2, hidden_layers=3, hidden_units=128, transforms=1,
+        mf.generate.build_generator("nsf", input_features=2, output_features=2, hidden_layers=3, hidden_units=129, transforms=1,
                                     bins=8)
     gen = mf.generate.build_generator("nsf", input_features=2, output_features=2, hidden_layers=3, hidden_units=64,
                                       transforms=1, bins=22).to(backend)

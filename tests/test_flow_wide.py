@@ -1,0 +1,141 @@
+"""Wide conditioners (hidden_units 65 .. 128 and / or 8 .. 16 features: mentflow_amd/csrc/flow_wide.hip) against the oracle.
+
+mentflow/generate/build.py:36-38 takes hidden_units / hidden_layers from the config and zuko accepts any width; the 64-wide
+kernels keep a layer's weights in LDS, which 128 units do not fit, so these shapes run the `mf_flow_wide_*` family: weights in
+global memory as MFMA fragment blocks, tile-granular mask sparsity, two-kernel backward.  Same gates as the 64-wide "steep" cases
+of tests/test_flow_kernels.py (x 5e-5, log_prob 5e-4, gradients 2e-3 of the largest entry, each widened to 3x the fp32 oracle's own
+error against the fp64 one where the steep weights make fp32 itself that inaccurate)."""
+import numpy as np
+import pytest
+import torch
+
+import mentflow_amd as mf
+from mentflow_amd.generate import packing
+from oracle import flow as of
+from oracle.harness import flow_spec_from_generator
+
+
+def steep_generator(backend, kind, d, units, layers, bins, transforms=2, seed=5):
+    torch.manual_seed(seed)
+    kws = dict(input_features=d, output_features=d, hidden_layers=layers, hidden_units=units, transforms=transforms)
+    if kind == "nsf":
+        kws["bins"] = bins
+    gen = mf.generate.build_generator(kind, **kws)
+    with torch.no_grad():
+        for layer in gen.layers:
+            lin = layer.linears()[-1]
+            lin.weight.mul_(4.0 * min(1.0, (64.0 / units) ** 0.5))   # the output scale of the 64-wide steep cases
+            lin.bias.add_(torch.randn_like(lin.bias))
+    return gen.to(backend)
+
+
+CASES = [("nsf", 6, 128, 3, 20), ("nsf", 6, 96, 2, 20), ("nsf", 3, 100, 3, 8), ("nsf", 2, 65, 1, 20), ("nsf", 4, 128, 4, 13),
+         ("nsf", 8, 64, 3, 20), ("nsf", 12, 128, 2, 8), ("maf", 4, 128, 3, 0), ("maf", 9, 80, 2, 0), ("maf", 16, 128, 1, 0)]
+
+
+@pytest.mark.parametrize("kind,d,units,layers,bins", CASES)
+def test_wide_conditioner_matches_oracle(backend, kind, d, units, layers, bins):
+    gen = steep_generator(backend, kind, d, units, layers, bins)
+    assert gen.wide and all(lin.weight.shape[0] == units for layer in gen.layers for lin in layer.linears()[:-1])
+    n = 300 if backend.type == "cuda" else 150
+    torch.manual_seed(6)
+    z = torch.randn(n, d) * 1.5
+    z[0, 0], z[1, d - 1] = 6.0, -5.5                         # outside the spline domain
+    wx, wl = torch.randn(n, d), torch.randn(n)
+    x, lp = gen.sample_and_log_prob(n, z=z.to(backend))
+    ((x * wx.to(backend)).sum() + (lp * wl.to(backend)).sum()).backward()
+    gk = torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).cpu()
+    s64 = flow_spec_from_generator(gen, torch.float64)
+    ps = s64.parameters()
+    for p in ps:
+        p.requires_grad_(True)
+    xo, lo = of.sample_and_log_prob(z.double(), s64)
+    ((xo * wx.double()).sum() + (lo * wl.double()).sum()).backward()
+    go = torch.cat([p.grad.reshape(-1) for p in ps])
+    with torch.no_grad():
+        x32, l32 = of.sample_and_log_prob(z, flow_spec_from_generator(gen, torch.float32))
+    ex32, el32 = float((x32.double() - xo.detach()).abs().max()), float((l32.double() - lo.detach()).abs().max())
+    assert (x.detach().cpu() - xo.detach()).abs().max() < max(5e-5, 3 * ex32)
+    assert (lp.detach().cpu() - lo.detach()).abs().max() < max(5e-4, 3 * el32)
+    err = float((gk.double() - go).abs().max() / go.abs().max())
+    assert err < 2e-3, f"gradient error {err:.2e} of max"
+    for layer in gen.layers:
+        for lin in layer.linears():
+            assert (lin.weight.grad.cpu()[~lin.mask.cpu()] == 0).all()
+    # the inverse of a steep stack is ill conditioned: check the well-conditioned round trip F(F^-1(x)) = x
+    with torch.no_grad():
+        zb = gen.inverse(x.detach())
+        xr, _ = gen.sample_and_log_prob(n, z=zb)
+    assert (xr.cpu() - x.detach().cpu()).abs().max() < 2e-5 * max(1.0, float(x.detach().abs().max()))
+
+
+def test_wide_dz_and_chunked_backward(backend):
+    """dL/dz through the wide backward (gx of layer 0 + the base-density term) and a backward cut into chunks with a ragged tail
+    (slab rows of two size classes) equal the one-launch result / the oracle."""
+    gen = steep_generator(backend, "nsf", 5, 128, 3, 20, seed=7)
+    n = 203
+    torch.manual_seed(8)
+    z = (torch.randn(n, 5) * 1.2)
+    wx, wl = torch.randn(n, 5), torch.randn(n)
+
+    def run(chunk):
+        gen.zero_grad(set_to_none=True)
+        gen.spec().bwd_chunk = chunk
+        zz = z.to(backend).clone().requires_grad_(True)
+        x, lp = gen.sample_and_log_prob(n, z=zz)
+        ((x * wx.to(backend)).sum() + (lp * wl.to(backend)).sum()).backward()
+        return zz.grad.cpu(), torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).cpu()
+
+    gz1, gp1 = run(1 << 20)
+    gz2, gp2 = run(96)
+    assert torch.equal(gz1, gz2)
+    assert (gp1 - gp2).abs().max() <= 2e-6 * gp1.abs().max()
+    s64 = flow_spec_from_generator(gen, torch.float64)
+    zo = z.double().requires_grad_(True)
+    xo, lo = of.sample_and_log_prob(zo, s64)
+    ((xo * wx.double()).sum() + (lo * wl.double()).sum()).backward()
+    assert float((gz1.double() - zo.grad).abs().max() / zo.grad.abs().max()) < 2e-3
+
+
+def test_wide_packing_covers_every_parameter_once():
+    """Host logic: every unmasked weight sits in the wide weight image twice (forward + transposed fragments), every bias once,
+    masked weights nowhere; the gradient image holds every unmasked parameter exactly once; the library's layout sizes agree."""
+    from mentflow_amd.generate.masks import conditioner_masks
+    for d, width, L, K in [(6, 128, 3, 20), (9, 70, 2, 8), (2, 128, 1, 20)]:
+        masks = [m.cpu() for m in conditioner_masks(torch.arange(d), (width,) * L, 3 * K - 1)]
+        sizes = []
+        for m in masks:
+            sizes += [m.numel(), m.shape[0]]
+        offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()
+        img, gparam, gpos = packing.wide_image_index(d, L, "rqs", K, masks, offsets)
+        assert img.size == packing.wide_layout(L, d)["total"]
+        cnt = np.bincount(img[img >= 0], minlength=sum(sizes))
+        off = 0
+        for m in masks:
+            w = cnt[off:off + m.numel()].reshape(m.shape)
+            off += m.numel()
+            b = cnt[off:off + m.shape[0]]
+            off += m.shape[0]
+            mm = m.numpy().astype(bool)
+            assert (w[mm] == 2).all() and (w[~mm] == 0).all() and (b == 1).all()
+        assert len(set(gpos.tolist())) == gpos.size and gpos.max() < packing.wide_grad_layout(L, d)["total"]
+        assert sorted(gparam.tolist()) == sorted(np.nonzero(cnt)[0].tolist())
+
+
+def test_wide_limits_and_refusals(backend):
+    from mentflow_amd import _lib
+    import ctypes
+    lib = _lib.get_lib()
+    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib.mf_flow_wide_limits(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+    assert (a.value, b.value, c.value) == (packing.WIDE_DMAX, packing.WIDE_HP, 4)
+    assert lib.mf_flow_wide_image_floats(3, 6) == packing.wide_layout(3, 6)["total"]
+    assert lib.mf_flow_wide_grad_floats(3, 6) == packing.wide_grad_layout(3, 6)["total"]
+    with pytest.raises(NotImplementedError, match="hidden_units <= 128"):
+        mf.generate.build_generator("nsf", input_features=4, output_features=4, hidden_layers=3, hidden_units=160, transforms=1, bins=20)
+    with pytest.raises(NotImplementedError, match="up to 16 features"):
+        mf.generate.build_generator("nsf", input_features=17, output_features=17, hidden_layers=2, hidden_units=64, transforms=1, bins=8)
+    gen = mf.generate.build_generator("nsf", input_features=4, output_features=4, hidden_layers=5, hidden_units=128, transforms=1,
+                                      bins=20).to(backend)
+    with pytest.raises(RuntimeError, match="hidden_layers"):
+        gen.sample(64)
