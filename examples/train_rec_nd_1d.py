@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--batch-size", type=int, default=25000)
     ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--hidden-units", type=int, default=64, help="config/gen/flow.yaml:3; above 64 the wide kernel family runs")
+    ap.add_argument("--hidden-layers", type=int, default=3)
     ap.add_argument("--graphed", action="store_true",
                     help="replay each iteration from a per-epoch hipGraph (mentflow_amd.graph) with a fused AdamW: the "
                          "launch-bound 25 000-particle regime, 0.77 ms instead of 1.2 ms per step")
@@ -37,7 +39,8 @@ def main():
 
     dev = torch.device("cuda", 0)
     prob = build_problem(ndim=args.ndim, num=args.meas_num, bins=args.bins, xmax=args.xmax, seed=args.seed, transforms=5,
-                         prior_scale=1.0, device=dev, dist_name=args.dist, meas_samples=1_000_000)
+                         prior_scale=1.0, device=dev, dist_name=args.dist, meas_samples=1_000_000, hidden_units=args.hidden_units,
+                         hidden_layers=args.hidden_layers)
     model = prob.model
     torch.manual_seed(args.seed)                                               # experiments/setup.py:163-164
     # setup.py:166-170; graphed: capturable + fused (the capturable foreach AdamW launches ~130 tiny kernels per step)
