@@ -109,6 +109,36 @@ static void flow_affine(int d, int L, int64_t n, bool fused) {
     printf("  affine d=%d L=%d n=%ld %s\n", d, L, (long)n, fused ? "fused" : "two-kernel");
 }
 
+// wide conditioner family (ABI 5): exactly-sized image / scratch / slab buffers, so that a fragment block, a scratch tile or a slab
+// position addressed out of range runs into ASan's redzone
+static void flow_wide(int d, int hidden, int L, int K, int64_t n) {
+    const int nblk = K ? d : 1;
+    const int64_t F = mf_flow_wide_image_floats(L, nblk), G = mf_flow_wide_grad_floats(L, nblk);
+    std::vector<float> image = rnd(F, 0.3f);
+    std::vector<int32_t> order(d);
+    for (int i = 0; i < d; ++i) order[i] = d - 1 - i;
+    std::vector<float> x = rnd(n * d, 2.0f), y(n * d), logp(n), x2(n * d);
+    x[0] = 7.0f;
+    CK(mf_flow_wide_layer_fwd(image.data(), d, hidden, L, K, order.data(), x.data(), n, y.data(), nullptr, logp.data(), 1, nullptr));
+    CK(mf_flow_wide_layer_fwd(image.data(), d, hidden, L, K, nullptr, x.data(), n, y.data(), logp.data(), logp.data(), 0, nullptr));
+    all_finite(y, "wide y");
+    all_finite(logp, "wide logp");
+    std::vector<float> gy = rnd(n * d, 1.0f), gl = rnd(n, 1.0f), gx(n * d);
+    const int rows = mf_flow_wide_bwd_slab_rows(n);
+    const int64_t sf = mf_flow_wide_bwd_scratch_floats(n, d, L, K);
+    std::vector<float> slab((size_t)rows * G, NAN), scratch((size_t)sf, NAN);
+    CK(mf_flow_wide_layer_bwd(image.data(), d, hidden, L, K, order.data(), x.data(), n, gy.data(), gl.data(), gx.data(), slab.data(),
+                              rows, 0, scratch.data(), sf, nullptr));
+    all_finite(scratch, "wide scratch");                   // every tile of the scratch was written
+    CK(mf_flow_wide_layer_bwd(image.data(), d, hidden, L, K, order.data(), x.data(), n, gy.data(), gl.data(), nullptr, slab.data(),
+                              rows, 1, scratch.data(), sf, nullptr));
+    all_finite(gx, "wide gx");
+    CK(mf_flow_wide_layer_inv(image.data(), d, hidden, L, K, order.data(), y.data(), n, x2.data(), nullptr));
+    all_finite(x2, "wide inverse");
+    printf("  wide d=%d hidden=%d L=%d bins=%d n=%ld: image %ld, gradient image %ld floats, slab rows %d, scratch %ld floats\n", d, hidden,
+           L, K, (long)n, (long)F, (long)G, rows, (long)sf);
+}
+
 static std::vector<float> centres(int B, float lo, float hi, std::vector<float>* edges = nullptr) {
     std::vector<float> e(B + 1), c(B);
     for (int i = 0; i <= B; ++i) e[i] = lo + (hi - lo) * (float)i / (float)B;
@@ -207,6 +237,10 @@ int main(int argc, char** argv) {
     flow_rqs(5, 3, 8, 33, false);
     flow_affine(2, 3, 200, true);
     flow_affine(7, 2, 45, false);
+    flow_wide(6, 128, 3, 20, 150);       // four hidden tiles, ragged last particle tile
+    flow_wide(9, 70, 2, 8, 70);          // three tiles in use, two input-layer k-groups
+    flow_wide(3, 128, 4, 13, 40);        // run-time bins, four hidden layers
+    flow_wide(16, 100, 1, 0, 90);        // affine, widest input
     printf("KDE kernels\n");
     kde1d(1500, 6, 7, 64, 0.5f, 4);      // factorised radius-4 window
     kde1d(700, 3, 5, 85, 0.6f, 5);       // runtime radius
