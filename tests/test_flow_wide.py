@@ -139,3 +139,45 @@ def test_wide_limits_and_refusals(backend):
                                       bins=20).to(backend)
     with pytest.raises(RuntimeError, match="hidden_layers"):
         gen.sample(64)
+
+
+@pytest.mark.gpu
+def test_wide_graphed_step_equals_eager():
+    """A 128-unit MENT step replayed from a hipGraph (mentflow_amd.graph) reproduces the eager steps bit for bit: the wide kernels
+    are deterministic as well (slab rows reduced in a fixed order, no float atomics) and the step has no host synchronisation."""
+    import copy
+    from mentflow_amd import _lib
+    from mentflow_amd.harness import build_problem
+    _lib.use_library(_lib.DEFAULT_PATH)
+    dev = torch.device("cuda", 0)
+    n = 25_000
+    prob = build_problem(ndim=6, num=25, bins=64, xmax=4.0, seed=2, transforms=5, prior_scale=1.0, device=dev, dist_name="rings",
+                         meas_samples=200_000, penalty_parameter=100.0, hidden_units=128)
+    model = prob.model
+    assert model.generator.wide
+    state0 = copy.deepcopy(model.state_dict())
+    torch.manual_seed(0)
+    z = torch.randn(n, 6, device=dev)
+
+    def run(graphed):
+        model.load_state_dict(state0)
+        model.generator.inject_z = z
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0, capturable=True)
+        if graphed:
+            g = mf.graph.GraphedTrainStep(model, opt, n, warmup=3)
+            outs = [g.step()[0].clone() for _ in range(3)]
+        else:
+            outs = []
+            for _ in range(3):
+                opt.zero_grad(set_to_none=False)
+                L, H, D = model.loss(n)
+                L.backward()
+                opt.step()
+                outs.append(L.detach().clone())
+        return outs, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+
+    eager, pe = run(False)
+    graphed, pg = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(eager, graphed))
+    assert torch.equal(pe, pg)
+    assert float(eager[2]) < float(eager[0])
