@@ -21,6 +21,8 @@ def _free_port():
 def _problem(device, gen_name="nsf"):
     from mentflow_amd.harness import build_problem
     kws = dict(gen_name="nn", discrepancy="mae", hidden_layers=2, hidden_units=16) if gen_name == "nn" else {}
+    if gen_name == "nsf-wide":                     # the wide kernel family (hidden_units > 64): same data-parallel plumbing
+        kws = dict(gen_name="nsf", hidden_units=96, hidden_layers=2)
     return build_problem(ndim=6, num=5, bins=16, xmax=4.0, seed=2, transforms=2, prior_scale=1.0, device=device,
                          meas_samples=4000, penalty_parameter=50.0, **kws)
 
@@ -44,13 +46,15 @@ def _worker(rank, world, port, z, out, gen_name="nsf"):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one(emu_library):
+@pytest.mark.parametrize("gen_name", ["nsf", "nsf-wide"])
+def test_two_ranks_equal_one(emu_library, gen_name):
     from mentflow_amd import _lib
     _lib.use_library(emu_library)
     torch.manual_seed(7)
     n = 101                                       # odd on purpose: ranks get 51 and 50 particles
     z = torch.randn(n, 6)
-    prob = _problem(torch.device("cpu"))
+    prob = _problem(torch.device("cpu"), gen_name)
+    assert prob.model.generator.wide == (gen_name == "nsf-wide")
     prob.model.generator.inject_z = z
     L, H, D = prob.model.loss(n)
     L.backward()
@@ -58,7 +62,7 @@ def test_two_ranks_equal_one(emu_library):
 
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), z, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), z, out, gen_name), nprocs=2, join=True)
     assert set(out.keys()) == {0, 1}
     for r in (0, 1):
         Lr, Hr, Dr, gr = out[r]
