@@ -150,10 +150,29 @@ __device__ __forceinline__ void frag_mfma(f32x16_t& acc, const Frag& f, const B&
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = mfma(f.a[g][j], b[4 * g + j], acc);
 }
+// two blocks that are neighbours in the image (consecutive input tiles of one output tile / consecutive k tiles): 8 KiB
+struct Frag2 {
+    wf4 a[8];
+};
+__device__ __forceinline__ void frag2_load(Frag2& f, gfp blk, int lane) {
+    const MF_GLOBAL char* q = (const MF_GLOBAL char*)blk;
+    const unsigned off = (unsigned)lane * 16u;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) f.a[g] = *(const MF_GLOBAL wf4*)(q + (off + 1024u * g));
+}
+template <int HALF, class B>
+__device__ __forceinline__ void frag2_mfma(f32x16_t& acc, const Frag2& f, const B& b) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = mfma(f.a[4 * HALF + g][j], b[4 * g + j], acc);
+}
 // One block at a time (load, wait, 16 MFMAs): only where a single block is needed.  Chains of blocks go through the rolling
-// prefetch below: the fragments of block k + 1 are requested before the MFMAs of block k (1 024 cycles of matrix pipe against
-// an L2 round trip of a few hundred), across the output tiles of a layer — the mask bounds are wave-uniform, so "the next
-// active block" is known when the current one starts.  -DMF_WIDE_NO_PREFETCH builds the plain form (A/B runs).
+// prefetch below, in PAIRS of neighbouring blocks: the fragments of pair k + 1 (8 KiB) are requested before the MFMAs of pair k
+// (up to 2 048 cycles of matrix pipe against an L2 round trip that exceeds the 1 024 cycles of a single block when 256 CUs read
+// the same image), across the output tiles of a layer — the mask bounds are wave-uniform, so "the next active pair" is known when
+// the current one starts; the second block of a pair is fetched even when the masks switch its MFMAs off (zeros, never used).
+// -DMF_WIDE_NO_PREFETCH builds the plain form (A/B runs).
 template <class B>
 __device__ __forceinline__ void wide_block(f32x16_t& acc, gfp blk, int lane, const B& b) {
     Frag f;
@@ -211,6 +230,7 @@ __device__ __forceinline__ void wide_input(gfp img, const WideLayout& g, int d, 
 }
 
 // out = relu(W in + b) of one hidden layer (H = that layer's F | T | B)
+template <bool PAIR>
 __device__ __forceinline__ void wide_hidden(gfp H, const f32x16_t (&in)[WIDE_HT], f32x16_t (&out)[WIDE_HT],
                                             int lane, int hh, const WideSp& sp) {
     const gfp B = H + 2 * WIDE_HT * WIDE_HT * WIDE_FB;
@@ -229,6 +249,29 @@ __device__ __forceinline__ void wide_hidden(gfp H, const f32x16_t (&in)[WIDE_HT]
         }
     }
 #else
+    if constexpr (PAIR) {
+        Frag2 cur, nxt;
+        frag2_load(cur, H, lane);                                 // pair (0, 0): every tile in use has at least one input tile
+#pragma unroll
+        for (int rt = 0; rt < WIDE_HT; ++rt) {
+            if (rt < sp.ht) {
+                f32x16_t acc = wide_bias(B, rt, hh);
+#pragma unroll
+                for (int pr = 0; pr < WIDE_HT / 2; ++pr)
+                    if (2 * pr < sp.nin_h[rt]) {
+                        if (pr + 1 < WIDE_HT / 2 && 2 * (pr + 1) < sp.nin_h[rt]) frag2_load(nxt, H + (rt * WIDE_HT + 2 * (pr + 1)) * WIDE_FB, lane);
+                        else if (rt + 1 < WIDE_HT && rt + 1 < sp.ht) frag2_load(nxt, H + (rt + 1) * WIDE_HT * WIDE_FB, lane);
+                        frag2_mfma<0>(acc, cur, TileB{in[2 * pr]});
+                        if (2 * pr + 1 < sp.nin_h[rt]) frag2_mfma<1>(acc, cur, TileB{in[2 * pr + 1]});
+                        cur = nxt;
+                    }
+                wide_relu(acc);
+                out[rt] = acc;
+            } else {
+                out[rt] = wide_zero();
+            }
+    }
+    } else {
     Frag cur, nxt;
     frag_load(cur, H, lane);                                  // block (0, 0): every tile in use has at least one input tile
 #pragma unroll
@@ -249,18 +292,57 @@ __device__ __forceinline__ void wide_hidden(gfp H, const f32x16_t (&in)[WIDE_HT]
             out[rt] = wide_zero();
         }
     }
+    }
 #endif
 }
 
 // v = (output block) h + b : NRT row tiles of the block (2: the 64 spline slots of both halves; 1: the affine block)
-template <int NRT>
+template <int NRT, bool PAIR>
 __device__ __forceinline__ void wide_out_block(gfp blk, const f32x16_t (&h)[WIDE_HT], float (&v)[32], int lane,
                                                int hh, int nin) {
     const gfp B = blk + 4 * WIDE_HT * WIDE_FB;
+#ifdef MF_WIDE_NO_PREFETCH
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        if (rt < NRT) {
+            f32x16_t acc = wide_bias(B, rt, hh);
+#pragma unroll
+            for (int it = 0; it < WIDE_HT; ++it)
+                if (it < nin) wide_block(acc, blk + (rt * WIDE_HT + it) * WIDE_FB, lane, TileB{h[it]});
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[16 * rt + r] = acc[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[16 * rt + r] = 0.0f;
+        }
+    }
+#else
+    if constexpr (PAIR) {
+        Frag2 cur, nxt;
+        if (nin > 0) frag2_load(cur, blk, lane);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            if (rt < NRT) {
+                f32x16_t acc = wide_bias(B, rt, hh);
+#pragma unroll
+                for (int pr = 0; pr < WIDE_HT / 2; ++pr)
+                    if (2 * pr < nin) {
+                        if (pr + 1 < WIDE_HT / 2 && 2 * (pr + 1) < nin) frag2_load(nxt, blk + (rt * WIDE_HT + 2 * (pr + 1)) * WIDE_FB, lane);
+                        else if (rt + 1 < NRT) frag2_load(nxt, blk + (rt + 1) * WIDE_HT * WIDE_FB, lane);
+                        frag2_mfma<0>(acc, cur, TileB{h[2 * pr]});
+                        if (2 * pr + 1 < nin) frag2_mfma<1>(acc, cur, TileB{h[2 * pr + 1]});
+                        cur = nxt;
+                    }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[16 * rt + r] = acc[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[16 * rt + r] = 0.0f;
+            }
+    }
+    } else {
     Frag cur, nxt;
-#ifndef MF_WIDE_NO_PREFETCH
     if (nin > 0) frag_load(cur, blk, lane);
-#endif
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         if (rt < NRT) {
@@ -268,15 +350,10 @@ __device__ __forceinline__ void wide_out_block(gfp blk, const f32x16_t (&h)[WIDE
 #pragma unroll
             for (int it = 0; it < WIDE_HT; ++it)
                 if (it < nin) {
-#ifdef MF_WIDE_NO_PREFETCH
-                    frag_load(cur, blk + (rt * WIDE_HT + it) * WIDE_FB, lane);
-                    frag_mfma(acc, cur, TileB{h[it]});
-#else
                     if (it + 1 < WIDE_HT && it + 1 < nin) frag_load(nxt, blk + (rt * WIDE_HT + it + 1) * WIDE_FB, lane);
                     else if (rt + 1 < NRT) frag_load(nxt, blk + (rt + 1) * WIDE_HT * WIDE_FB, lane);
                     frag_mfma(acc, cur, TileB{h[it]});
                     cur = nxt;
-#endif
                 }
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[16 * rt + r] = acc[r];
@@ -285,6 +362,8 @@ __device__ __forceinline__ void wide_out_block(gfp blk, const f32x16_t (&h)[WIDE
             for (int r = 0; r < 16; ++r) v[16 * rt + r] = 0.0f;
         }
     }
+    }
+#endif
 }
 
 // the affine transform's parameters of feature i out of the block's slots: slot i of half 0 = shift_i, of half 1 = scale_i
@@ -320,7 +399,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(2, 2) void wide_fwd_k
 #pragma unroll 1
         for (int l = 1; l < L; ++l) {
             f32x16_t t[WIDE_HT];
-            wide_hidden(image + g.offH + (l - 1) * g.strideH, h, t, lane, hh, sp);
+            wide_hidden<false>(image + g.offH + (l - 1) * g.strideH, h, t, lane, hh, sp);
 #pragma unroll
             for (int rt = 0; rt < WIDE_HT; ++rt) h[rt] = t[rt];
         }
@@ -329,7 +408,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(2, 2) void wide_fwd_k
 #pragma unroll 1
             for (int i = 0; i < d; ++i) {
                 float v[32], gdummy[32];
-                wide_out_block<2>(image + g.off3 + i * g.stride3, h, v, lane, hh, sp.nin3[i]);
+                wide_out_block<2, false>(image + g.off3 + i * g.stride3, h, v, lane, hh, sp.nin3[i]);
                 float yi, li, gxd;
                 rqs_apply<K, 0>(v, xp[i], hh, yi, li, 0.0f, 0.0f, gdummy, gxd, bins_rt);
                 ladj += li;
@@ -337,7 +416,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(2, 2) void wide_fwd_k
             }
         } else {
             float v[32];
-            wide_out_block<1>(image + g.off3, h, v, lane, hh, sp.ht);
+            wide_out_block<1, false>(image + g.off3, h, v, lane, hh, sp.ht);
 #pragma unroll 1
             for (int i = 0; i < d; ++i) {
                 float shift, scale;
@@ -421,7 +500,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
         for (int l = 1; l < WIDE_LMAX; ++l) {
             if (l < L) {
                 f32x16_t t[WIDE_HT];
-                wide_hidden(image + g.offH + (l - 1) * g.strideH, h, t, lane, hh, sp);
+                wide_hidden<true>(image + g.offH + (l - 1) * g.strideH, h, t, lane, hh, sp);
 #pragma unroll
                 for (int rt = 0; rt < WIDE_HT; ++rt) {
                     h[rt] = t[rt];
@@ -445,7 +524,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
                 float v[32], gv[32];
                 const gfp blk = image + g.off3 + i * g.stride3;
                 const int nin = sp.nin3[i];
-                wide_out_block<2>(blk, h, v, lane, hh, nin);
+                wide_out_block<2, true>(blk, h, v, lane, hh, nin);
                 const float gyi = valid ? gy[pc * d + i] : 0.0f;
                 float yi, li, gxd;
                 rqs_apply<K, 1>(v, xp[i], hh, yi, li, gyi, gl, gv, gxd, bins_rt);
@@ -464,16 +543,14 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
                         wide_block(gh[it], T + (it * 2 + 1) * WIDE_FB, lane, SlotB<16>{gv});
                     }
 #else
-                Frag cur, nxt;
-                if (nin > 0) frag_load(cur, T, lane);
+                Frag2 cur, nxt;
+                if (nin > 0) frag2_load(cur, T, lane);
 #pragma unroll
                 for (int it = 0; it < WIDE_HT; ++it)
                     if (it < nin) {
-                        frag_load(nxt, T + (it * 2 + 1) * WIDE_FB, lane);
-                        frag_mfma(gh[it], cur, SlotB<0>{gv});
-                        cur = nxt;
-                        if (it + 1 < WIDE_HT && it + 1 < nin) frag_load(nxt, T + (it + 1) * 2 * WIDE_FB, lane);
-                        frag_mfma(gh[it], cur, SlotB<16>{gv});
+                        if (it + 1 < WIDE_HT && it + 1 < nin) frag2_load(nxt, T + (it + 1) * 2 * WIDE_FB, lane);
+                        frag2_mfma<0>(gh[it], cur, SlotB<0>{gv});
+                        frag2_mfma<1>(gh[it], cur, SlotB<16>{gv});
                         cur = nxt;
                     }
 #endif
@@ -481,7 +558,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
         } else {
             float v[32], gv[32];
             const gfp blk = image + g.off3;
-            wide_out_block<1>(blk, h, v, lane, hh, sp.ht);
+            wide_out_block<1, true>(blk, h, v, lane, hh, sp.ht);
 #pragma unroll
             for (int m = 0; m < 32; ++m) gv[m] = 0.0f;
 #pragma unroll
@@ -529,19 +606,20 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
                     }
                 }
 #else
-                Frag cur, nxt;
-                frag_load(cur, T, lane);                          // block (0, 0): kbeg_t[0] = 0
+                Frag2 cur, nxt;
+                frag2_load(cur, T, lane);                         // pair (0, 0): kbeg_t[0] = 0
 #pragma unroll
                 for (int it = 0; it < WIDE_HT; ++it) {
                     t[it] = wide_zero();
                     if (it < sp.ht) {
 #pragma unroll
-                        for (int kt = 0; kt < WIDE_HT; ++kt)
-                            if (kt >= sp.kbeg_t[it] && kt < sp.ht) {
-                                if (kt + 1 < WIDE_HT && kt + 1 < sp.ht) frag_load(nxt, T + (it * WIDE_HT + kt + 1) * WIDE_FB, lane);
+                        for (int pr = 0; pr < WIDE_HT / 2; ++pr)
+                            if (2 * pr + 1 >= sp.kbeg_t[it] && 2 * pr < sp.ht) {
+                                if (pr + 1 < WIDE_HT / 2 && 2 * (pr + 1) < sp.ht) frag2_load(nxt, T + (it * WIDE_HT + 2 * (pr + 1)) * WIDE_FB, lane);
                                 else if (it + 1 < WIDE_HT && it + 1 < sp.ht)
-                                    frag_load(nxt, T + ((it + 1) * WIDE_HT + sp.kbeg_t[it + 1 < WIDE_HT ? it + 1 : it]) * WIDE_FB, lane);
-                                frag_mfma(t[it], cur, TileB{gh[kt]});
+                                    frag2_load(nxt, T + ((it + 1) * WIDE_HT + (sp.kbeg_t[it + 1 < WIDE_HT ? it + 1 : it] & ~1)) * WIDE_FB, lane);
+                                if (2 * pr >= sp.kbeg_t[it]) frag2_mfma<0>(t[it], cur, TileB{gh[2 * pr]});
+                                if (2 * pr + 1 < sp.ht) frag2_mfma<1>(t[it], cur, TileB{gh[2 * pr + 1]});
                                 cur = nxt;
                             }
                     }
@@ -558,13 +636,14 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
         }
         if (gx != nullptr) {
             // gacc += W0^T gpre0 : rows = input features (lanes col < d carry weights, the image holds zeros elsewhere)
-            Frag cur, nxt;
-            frag_load(cur, image + g.offW0T, lane);
+            Frag2 cur, nxt;
+            frag2_load(cur, image + g.offW0T, lane);
 #pragma unroll
-            for (int kt = 0; kt < WIDE_HT; ++kt)
-                if (kt < sp.ht) {
-                    if (kt + 1 < WIDE_HT && kt + 1 < sp.ht) frag_load(nxt, image + g.offW0T + (kt + 1) * WIDE_FB, lane);
-                    frag_mfma(gacc, cur, TileB{gh[kt]});
+            for (int pr = 0; pr < WIDE_HT / 2; ++pr)
+                if (2 * pr < sp.ht) {
+                    if (pr + 1 < WIDE_HT / 2 && 2 * (pr + 1) < sp.ht) frag2_load(nxt, image + g.offW0T + 2 * (pr + 1) * WIDE_FB, lane);
+                    frag2_mfma<0>(gacc, cur, TileB{gh[2 * pr]});
+                    if (2 * pr + 1 < sp.ht) frag2_mfma<1>(gacc, cur, TileB{gh[2 * pr + 1]});
                     cur = nxt;
                 }
             if (valid) {
@@ -765,7 +844,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(2, 2) void wide_inv_k
 #pragma unroll 1
                 for (int l = 1; l < L; ++l) {
                     f32x16_t tt[WIDE_HT];
-                    wide_hidden(image + g.offH + (l - 1) * g.strideH, h, tt, lane, hh, sp);
+                    wide_hidden<false>(image + g.offH + (l - 1) * g.strideH, h, tt, lane, hh, sp);
 #pragma unroll
                     for (int rt = 0; rt < WIDE_HT; ++rt) h[rt] = tt[rt];
                 }
@@ -776,11 +855,11 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(2, 2) void wide_inv_k
             float v[32];
             float xi;
             if constexpr (K != 0) {
-                wide_out_block<2>(image + g.off3 + blk * g.stride3, h, v, lane, hh, nin);
+                wide_out_block<2, false>(image + g.off3 + blk * g.stride3, h, v, lane, hh, nin);
                 float li, gxd, gdummy[32];
                 rqs_apply<K, 2>(v, yp[i], hh, xi, li, 0.0f, 0.0f, gdummy, gxd, bins_rt);
             } else {
-                wide_out_block<1>(image + g.off3, h, v, lane, hh, nin);
+                wide_out_block<1, false>(image + g.off3, h, v, lane, hh, nin);
                 float shift, scale;
                 wide_affine_params(v, i, hh, shift, scale);
                 xi = (yp[i] - shift) * fast_exp(-soft_clip(scale, LOG_SLOPE_INV));
