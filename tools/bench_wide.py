@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--num", type=int, default=100)
+    ap.add_argument("--bwd-chunk", type=int, default=None, help="particles per backward chunk (scratch = 4.6 KB per particle at 128 units)")
     ap.add_argument("--lib", default=None, help="another build of the library (A/B runs: tools/build_variant.sh)")
     args = ap.parse_args()
     if args.lib:
@@ -44,6 +45,8 @@ def main():
     model = prob.model
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0)
     n = args.per_gpu
+    if args.bwd_chunk:
+        model.generator.spec().bwd_chunk = args.bwd_chunk
 
     def step():
         opt.zero_grad()
