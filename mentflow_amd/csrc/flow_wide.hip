@@ -670,8 +670,17 @@ struct WideJobs {
     WideJob job[WIDE_MAXJOBS];
 };
 constexpr int WIDE_OA_WAVES = 4;
+// B column tiles per job.  2: 64 x 64 blocks, 136 registers, three waves per SIMD.  -DMF_WIDE_OA_FAT: 64 x 128 blocks (each A pair read
+// once per layer: 0.76 of the bytes) at 216 registers, two waves per SIMD — measured slower (11.7 vs 10.4 ms per step at 128 units).
+#ifdef MF_WIDE_OA_FAT
+constexpr int WIDE_OA_NB = WIDE_HT;
+#define MF_WIDE_OA_OCC 2
+#else
+constexpr int WIDE_OA_NB = 2;
+#define MF_WIDE_OA_OCC 3
+#endif
 
-__global__ __launch_bounds__(64 * WIDE_OA_WAVES) void wide_outer_accum_kernel(const float* __restrict__ scratch,
+__global__ __launch_bounds__(64 * WIDE_OA_WAVES) MF_WAVES_PER_SIMD(MF_WIDE_OA_OCC, MF_WIDE_OA_OCC) void wide_outer_accum_kernel(const float* __restrict__ scratch,
                                                                               const float* __restrict__ x, int64_t n, int d,
                                                                               float* __restrict__ gslab, int64_t gtotal,
                                                                               int accumulate, WideJobs jobs) {
@@ -682,12 +691,12 @@ __global__ __launch_bounds__(64 * WIDE_OA_WAVES) void wide_outer_accum_kernel(co
     float* gimage = gslab + (int64_t)blockIdx.x * gtotal;
     const int64_t ntiles = (n + 31) / 32;
     const bool from_x = jb.b_base < 0;
-    const bool two = jb.nb > 1;
-    f32x16_t acc[2][2];
+    const int nb = jb.nb;
+    f32x16_t acc[2][WIDE_OA_NB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = wide_zero();
+        for (int b = 0; b < WIDE_OA_NB; ++b) acc[a][b] = wide_zero();
     float bsum0 = 0.0f, bsum1 = 0.0f;
     const float* A = scratch + jb.a_base;
     const float* B = scratch + (from_x ? 0 : jb.b_base);
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(64 * WIDE_OA_WAVES) void wide_outer_accum_kernel(co
         for (int half = 0; half < 2; ++half) {
             const float4* pa0 = reinterpret_cast<const float4*>(A + tile * jb.a_ts + col * 32 + 16 * hh) + 2 * half;
             const float4* pa1 = reinterpret_cast<const float4*>(A + tile * jb.a_ts + (32 + col) * 32 + 16 * hh) + 2 * half;
-            float4 a0[2], a1[2], b0[2], b1[2];
+            float4 a0[2], a1[2], bq[WIDE_OA_NB][2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 a0[q] = pa0[q];
@@ -712,35 +721,36 @@ __global__ __launch_bounds__(64 * WIDE_OA_WAVES) void wide_outer_accum_kernel(co
                         const int64_t p = tile * 32 + 16 * hh + 4 * (2 * half + q) + e;
                         t[e] = (col < d && p < n) ? x[p * d + col] : 0.0f;
                     }
-                    b0[q] = make_float4(t[0], t[1], t[2], t[3]);
-                    b1[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    bq[0][q] = make_float4(t[0], t[1], t[2], t[3]);
                 }
             } else {
-                const float4* pb0 = reinterpret_cast<const float4*>(B + tile * jb.b_ts + col * 32 + 16 * hh) + 2 * half;
-                const float4* pb1 = reinterpret_cast<const float4*>(B + tile * jb.b_ts + (32 + col) * 32 + 16 * hh) + 2 * half;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    b0[q] = pb0[q];
-                    b1[q] = two ? pb1[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
+                for (int tb = 0; tb < WIDE_OA_NB; ++tb)
+                    if (tb < nb) {
+                        const float4* pb = reinterpret_cast<const float4*>(B + tile * jb.b_ts + (32 * tb + col) * 32 + 16 * hh) + 2 * half;
+                        bq[tb][0] = pb[0];
+                        bq[tb][1] = pb[1];
+                    }
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const float av0[4] = {a0[q].x, a0[q].y, a0[q].z, a0[q].w};
                 const float av1[4] = {a1[q].x, a1[q].y, a1[q].z, a1[q].w};
-                const float bv0[4] = {b0[q].x, b0[q].y, b0[q].z, b0[q].w};
-                const float bv1[4] = {b1[q].x, b1[q].y, b1[q].z, b1[q].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     bsum0 += av0[e];
                     bsum1 += av1[e];
-                    acc[0][0] = mfma(av0[e], bv0[e], acc[0][0]);
-                    acc[1][0] = mfma(av1[e], bv0[e], acc[1][0]);
-                    if (two) {
-                        acc[0][1] = mfma(av0[e], bv1[e], acc[0][1]);
-                        acc[1][1] = mfma(av1[e], bv1[e], acc[1][1]);
-                    }
                 }
+#pragma unroll
+                for (int tb = 0; tb < WIDE_OA_NB; ++tb)
+                    if (tb < nb) {
+                        const float bv[4] = {bq[tb][q].x, bq[tb][q].y, bq[tb][q].z, bq[tb][q].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[0][tb] = mfma(av0[e], bv[e], acc[0][tb]);
+                            acc[1][tb] = mfma(av1[e], bv[e], acc[1][tb]);
+                        }
+                    }
             }
         }
     }
@@ -748,8 +758,8 @@ __global__ __launch_bounds__(64 * WIDE_OA_WAVES) void wide_outer_accum_kernel(co
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-            if (tb && !two) continue;
+        for (int tb = 0; tb < WIDE_OA_NB; ++tb) {
+            if (tb >= nb) continue;
             if (from_x && col >= d) continue;
             const int rhoB = from_x ? col : (32 * tb + rowmap(col & 15, col >> 4));
 #pragma unroll
@@ -786,18 +796,27 @@ static WideJobs make_wide_jobs(int64_t n, int L, int nblk, const WideSp& sp) {
     };
     for (int ap = 0; ap < npair; ++ap)                                                       // input layer: A = GPRE[0], B = x
         add(GPRE + ap * 2048, WIDE_TS, -1, 0, gg.offW0 + 64 * ap * WIDE_DMAX, WIDE_DMAX, gg.offB0 + 64 * ap, 1);
+    const int nbp = (sp.ht + WIDE_OA_NB - 1) / WIDE_OA_NB;                                   // B groups of WIDE_OA_NB column tiles
     for (int l = 1; l < L; ++l)                                                              // hidden: A = GPRE[l], B = ACT[l-1]
         for (int ap = 0; ap < npair; ++ap)
-            for (int bp = 0; bp < npair; ++bp)
-                add(GPRE + (int64_t)l * ntiles * WIDE_TS + ap * 2048, WIDE_TS, ACT + (int64_t)(l - 1) * ntiles * WIDE_TS + bp * 2048,
-                    WIDE_TS, gg.offH + (l - 1) * gg.strideH + 64 * ap * WIDE_HP + 64 * bp, WIDE_HP,
-                    bp == 0 ? gg.offH + (l - 1) * gg.strideH + WIDE_HP * WIDE_HP + 64 * ap : -1, 2 * bp + 1 < sp.ht ? 2 : 1);
+            for (int bp = 0; bp < nbp; ++bp) {
+                const int nb = sp.ht - WIDE_OA_NB * bp < WIDE_OA_NB ? sp.ht - WIDE_OA_NB * bp : WIDE_OA_NB;
+                add(GPRE + (int64_t)l * ntiles * WIDE_TS + ap * 2048, WIDE_TS,
+                    ACT + (int64_t)(l - 1) * ntiles * WIDE_TS + bp * WIDE_OA_NB * 1024, WIDE_TS,
+                    gg.offH + (l - 1) * gg.strideH + 64 * ap * WIDE_HP + 32 * WIDE_OA_NB * bp, WIDE_HP,
+                    bp == 0 ? gg.offH + (l - 1) * gg.strideH + WIDE_HP * WIDE_HP + 64 * ap : -1, nb);
+            }
     for (int blk = 0; blk < nblk; ++blk)                                                     // last layer: A = GPHI[blk], B = ACT[L-1]
-        for (int bp = 0; bp < npair; ++bp) {
-            if (bp > 0 && 2 * bp >= sp.nin3[blk]) continue;                                  // masked-out pair (bp 0 carries the bias)
-            add(GPHI + (int64_t)blk * ntiles * 2048, 2048, ACT + (int64_t)(L - 1) * ntiles * WIDE_TS + bp * 2048, WIDE_TS,
-                gg.off3 + blk * gg.stride3 + 64 * bp, WIDE_HP, bp == 0 ? gg.off3 + blk * gg.stride3 + 64 * WIDE_HP : -1,
-                2 * bp + 1 < sp.ht ? 2 : 1);
+        for (int bp = 0; bp < nbp; ++bp) {
+            // only the input tiles the block's mask lets through (bp 0 always runs: it carries the bias sums)
+            int nb = sp.nin3[blk] - WIDE_OA_NB * bp;
+            if (nb > WIDE_OA_NB) nb = WIDE_OA_NB;
+            if (nb <= 0) {
+                if (bp > 0) continue;
+                nb = 1;
+            }
+            add(GPHI + (int64_t)blk * ntiles * 2048, 2048, ACT + (int64_t)(L - 1) * ntiles * WIDE_TS + bp * WIDE_OA_NB * 1024, WIDE_TS,
+                gg.off3 + blk * gg.stride3 + 32 * WIDE_OA_NB * bp, WIDE_HP, bp == 0 ? gg.off3 + blk * gg.stride3 + 64 * WIDE_HP : -1, nb);
         }
     return J;
 }
