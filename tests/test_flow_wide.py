@@ -30,7 +30,7 @@ def steep_generator(backend, kind, d, units, layers, bins, transforms=2, seed=5)
 
 
 CASES = [("nsf", 6, 128, 3, 20), ("nsf", 6, 96, 2, 20), ("nsf", 3, 100, 3, 8), ("nsf", 2, 65, 1, 20), ("nsf", 4, 128, 4, 13),
-         ("nsf", 8, 64, 3, 20), ("nsf", 12, 128, 2, 8), ("maf", 4, 128, 3, 0), ("maf", 9, 80, 2, 0), ("maf", 16, 128, 1, 0)]
+         ("nsf", 8, 64, 3, 20), ("nsf", 9, 20, 2, 8), ("nsf", 12, 128, 2, 8), ("maf", 4, 128, 3, 0), ("maf", 9, 80, 2, 0), ("maf", 16, 128, 1, 0)]
 
 
 @pytest.mark.parametrize("kind,d,units,layers,bins", CASES)
