@@ -907,7 +907,13 @@ static int wide_check(int d, int hidden, int L, int bins, int64_t n) {
 static int wide_grid(int64_t n) {
     const int64_t ntiles = (n + 31) / 32;
     int64_t g = (ntiles + WIDE_BLOCK / 64 - 1) / (WIDE_BLOCK / 64);
-    if (g > 2 * NUM_CU) g = 2 * NUM_CU;
+    int64_t cap = 2 * NUM_CU;
+#ifdef MF_EMU
+    // emulator build only (tests): a small cap makes a wave walk several tiles at test sizes — the grid-stride path that a
+    // 512-workgroup grid only reaches past 65 536 particles
+    if (const char* e = getenv("MENTFLOW_EMU_WIDE_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
+#endif
+    if (g > cap) g = cap;
     return (int)(g < 1 ? 1 : g);
 }
 
