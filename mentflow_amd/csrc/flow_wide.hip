@@ -543,14 +543,18 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
                         wide_block(gh[it], T + (it * 2 + 1) * WIDE_FB, lane, SlotB<16>{gv});
                     }
 #else
-                Frag2 cur, nxt;
-                if (nin > 0) frag2_load(cur, T, lane);
+                // (single blocks here: a pair in flight on top of the spline's adjoint state spills 50 registers — 15.6 vs 16.0 ms per
+                // step; requesting the NEXT output block's first fragments ahead of this chain measured nothing: 15.7 vs 15.6)
+                Frag cur, nxt;
+                if (nin > 0) frag_load(cur, T, lane);
 #pragma unroll
                 for (int it = 0; it < WIDE_HT; ++it)
                     if (it < nin) {
-                        if (it + 1 < WIDE_HT && it + 1 < nin) frag2_load(nxt, T + (it + 1) * 2 * WIDE_FB, lane);
-                        frag2_mfma<0>(gh[it], cur, SlotB<0>{gv});
-                        frag2_mfma<1>(gh[it], cur, SlotB<16>{gv});
+                        frag_load(nxt, T + (it * 2 + 1) * WIDE_FB, lane);
+                        frag_mfma(gh[it], cur, SlotB<0>{gv});
+                        cur = nxt;
+                        if (it + 1 < WIDE_HT && it + 1 < nin) frag_load(nxt, T + (it + 1) * 2 * WIDE_FB, lane);
+                        frag_mfma(gh[it], cur, SlotB<16>{gv});
                         cur = nxt;
                     }
 #endif
