@@ -160,6 +160,20 @@ int mf_flow_wide_layer_bwd(const float* image, int d, int hidden, int hidden_lay
                            int slab_rows, int accumulate, float* scratch, int64_t scratch_floats, void* stream);
 int mf_flow_wide_layer_inv(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
                            const float* y, int64_t n, float* x, void* stream);
+/* Activation hand-off of the wide family (the counterpart of mf_flow_rqs_layer_fwd_save / _bwd_saved above): a training forward
+ * stores every hidden level (in the layout of the backward's scratch tiles, so that the parameter-gradient contraction reads them in
+ * place) and every output block's conditioner outputs into `act` (mf_flow_wide_act_floats(n, d, hidden_layers, bins) floats per layer
+ * and batch: 3 KB per particle at 128 units, d = 6, three hidden layers); mf_flow_wide_layer_bwd_saved then neither recomputes the
+ * conditioner nor re-writes its activations (half of the backward's MFMAs and a third of its scratch traffic).  The whole batch in one
+ * call: `x`, `act` and the scratch must cover the same n particles.  Same results as mf_flow_wide_layer_fwd / _bwd.                 */
+int64_t mf_flow_wide_act_floats(int64_t n, int d, int hidden_layers, int bins);
+int mf_flow_wide_layer_fwd_save(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
+                                const float* x, int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp,
+                                float* act, int64_t act_floats, void* stream);
+int mf_flow_wide_layer_bwd_saved(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
+                                 const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gslab,
+                                 int slab_rows, int accumulate, float* scratch, int64_t scratch_floats, const float* act,
+                                 int64_t act_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused linear projection + 1-D Gaussian-KDE histogram over P projections.

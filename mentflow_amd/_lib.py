@@ -61,6 +61,10 @@ PROTOTYPES = {
     "mf_flow_wide_layer_bwd": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr,
                                       _i64, _ptr]),
     "mf_flow_wide_layer_inv": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr]),
+    "mf_flow_wide_act_floats": (_i64, [_i64, _i32, _i32, _i32]),
+    "mf_flow_wide_layer_fwd_save": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32, _ptr, _i64, _ptr]),
+    "mf_flow_wide_layer_bwd_saved": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr,
+                                            _i64, _ptr, _i64, _ptr]),
     "mf_proj_kde_ws_bytes": (_i64, [_i32, _i32]),
     "mf_proj_kde1d_fwd": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _i32, _f32, _i32, _ptr, _ptr, _ptr]),
     "mf_proj_kde1d_bwd": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _i32, _f32, _i32, _ptr, _ptr, _i32, _ptr]),

@@ -374,66 +374,7 @@ __device__ __forceinline__ void wide_affine_params(const float (&v)[32], int i, 
     half_pair(mine, hh, shift, scale);
 }
 
-// =========================================================================================== forward
-template <int K>      // K > 0 or RQS_ANY: rational-quadratic spline;  K == 0: affine
-__global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(2, 2) void wide_fwd_kernel(
-    const float* __restrict__ image_arg, int d, int L, const float* __restrict__ x, int64_t n, float* __restrict__ y,
-    const float* __restrict__ logp_in, float* __restrict__ logp_out, int init_logp, WideSp sp, int bins_rt) {
-    const int nblk = (K != 0) ? d : 1;
-    const WideLayout g = wide_layout(L, nblk);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
-    const int64_t ntiles = (n + 31) / 32;
-    for (int64_t tile = (int64_t)blockIdx.x * (WIDE_BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (WIDE_BLOCK / 64)) {
-        MF_NO_HOIST();                 // the image is loop invariant: keep its loads next to their MFMAs (flow_kernels.inc)
-        uint64_t image_u = (uint64_t)image_arg;
-        MF_OPAQUE_BASE(image_u);       // ... and its block addresses next to the loads (scalar adds), see MF_GLOBAL
-        const gfp image = (gfp)image_u;
-        const int64_t p = tile * 32 + col;
-        const bool valid = p < n;
-        const float* xp = x + (valid ? p : n - 1) * d;
-        float xb[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) xb[s] = (2 * s + hh < d) ? xp[2 * s + hh] : 0.0f;
-        f32x16_t h[WIDE_HT];
-        wide_input(image, g, d, xb, h, lane, hh, sp.ht);
-#pragma unroll 1
-        for (int l = 1; l < L; ++l) {
-            f32x16_t t[WIDE_HT];
-            wide_hidden<false>(image + g.offH + (l - 1) * g.strideH, h, t, lane, hh, sp);
-#pragma unroll
-            for (int rt = 0; rt < WIDE_HT; ++rt) h[rt] = t[rt];
-        }
-        float ladj = 0.0f;
-        if constexpr (K != 0) {
-#pragma unroll 1
-            for (int i = 0; i < d; ++i) {
-                float v[32], gdummy[32];
-                wide_out_block<2, false>(image + g.off3 + i * g.stride3, h, v, lane, hh, sp.nin3[i]);
-                float yi, li, gxd;
-                rqs_apply<K, 0>(v, xp[i], hh, yi, li, 0.0f, 0.0f, gdummy, gxd, bins_rt);
-                ladj += li;
-                if (valid && hh == 0) y[p * d + i] = yi;
-            }
-        } else {
-            float v[32];
-            wide_out_block<1, false>(image + g.off3, h, v, lane, hh, sp.ht);
-#pragma unroll 1
-            for (int i = 0; i < d; ++i) {
-                float shift, scale;
-                wide_affine_params(v, i, hh, shift, scale);
-                const float ls = soft_clip(scale, LOG_SLOPE_INV);
-                ladj += ls;
-                if (valid && hh == 0) y[p * d + i] = fmaf(xp[i], fast_exp(ls), shift);
-            }
-        }
-        if (valid && hh == 0) {
-            const float lp0 = init_logp ? base_log_prob(xp, d) : logp_in[p];
-            logp_out[p] = lp0 - ladj;
-        }
-    }
-}
-
-// =========================================================================================== backward
+// ------------------------------------------------------------------------------------------------------------
 // scratch tiles:  X[tile][c][particle], column c = 32 rt + 16 hh + r  <->  accumulator register r of row tile rt of lane half hh
 // (the layout of the 64-wide two-kernel path with more columns):  ACT[L][ntiles][HT*1024] | GPRE[L][ntiles][HT*1024] |
 // GPHI[nblk][ntiles][2048]
@@ -461,13 +402,120 @@ __device__ __forceinline__ void wide_mask(f32x16_t& gh, unsigned bits) {
     }
 }
 
-template <int K>
+__device__ __forceinline__ void wide_load(const float* __restrict__ src, int rt, int col, int hh, f32x16_t& a) {
+    const float* base = src + (32 * rt + 16 * hh) * 32 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = base[r * 32];
+}
+
+// Activation hand-off of the wide family (forward -> backward through HBM, as §4.2 of DESIGN.md does for the 64-wide kernels): a
+// training forward stores, per layer,  ACTH[L][ntiles][HT*1024]  — every hidden level in the SCRATCH-TILE layout, so that the
+// contraction kernel reads its B operands straight from it and the backward neither recomputes nor re-writes them — and
+// PHI[nblk][ntiles][2048]  — the conditioner outputs of every output block in the register layout of the wave (float4[8][lane]).
+// 3 KB per particle and layer at 128 units, d = 6, three hidden layers.
+__host__ __device__ inline int64_t wide_act_floats(int64_t ntiles, int L, int nblk) {
+    return ntiles * ((int64_t)L * WIDE_TS + (int64_t)nblk * 2048);
+}
+__device__ __forceinline__ void wide_phi_store(float* __restrict__ blk, int lane, const float (&v)[32]) {
+    act_f4* q = reinterpret_cast<act_f4*>(blk) + lane;
+#pragma unroll
+    for (int g4 = 0; g4 < 8; ++g4) {
+        const act_f4 t = {v[4 * g4], v[4 * g4 + 1], v[4 * g4 + 2], v[4 * g4 + 3]};
+        MF_ACT_ST(q + g4 * 64, t);
+    }
+}
+__device__ __forceinline__ void wide_phi_load(const float* __restrict__ blk, int lane, float (&v)[32]) {
+    const act_f4* q = reinterpret_cast<const act_f4*>(blk) + lane;
+#pragma unroll
+    for (int g4 = 0; g4 < 8; ++g4) {
+        const act_f4 t = MF_ACT_LD(q + g4 * 64);
+        v[4 * g4] = t.x;
+        v[4 * g4 + 1] = t.y;
+        v[4 * g4 + 2] = t.z;
+        v[4 * g4 + 3] = t.w;
+    }
+}
+
+// =========================================================================================== forward
+template <int K>      // K > 0 or RQS_ANY: rational-quadratic spline;  K == 0: affine
+__global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(2, 2) void wide_fwd_kernel(
+    const float* __restrict__ image_arg, int d, int L, const float* __restrict__ x, int64_t n, float* __restrict__ y,
+    const float* __restrict__ logp_in, float* __restrict__ logp_out, int init_logp, WideSp sp, int bins_rt,
+    float* __restrict__ act) {          // act != nullptr: training forward, hands the activations over (wide_act_floats)
+    const int nblk = (K != 0) ? d : 1;
+    const WideLayout g = wide_layout(L, nblk);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+    const int64_t ntiles = (n + 31) / 32;
+    float* const PHI = act + (int64_t)L * ntiles * WIDE_TS;
+    for (int64_t tile = (int64_t)blockIdx.x * (WIDE_BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (WIDE_BLOCK / 64)) {
+        MF_NO_HOIST();                 // the image is loop invariant: keep its loads next to their MFMAs (flow_kernels.inc)
+        uint64_t image_u = (uint64_t)image_arg;
+        MF_OPAQUE_BASE(image_u);       // ... and its block addresses next to the loads (scalar adds), see MF_GLOBAL
+        const gfp image = (gfp)image_u;
+        const int64_t p = tile * 32 + col;
+        const bool valid = p < n;
+        const float* xp = x + (valid ? p : n - 1) * d;
+        float xb[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xb[s] = (2 * s + hh < d) ? xp[2 * s + hh] : 0.0f;
+        f32x16_t h[WIDE_HT];
+        wide_input(image, g, d, xb, h, lane, hh, sp.ht);
+        if (act != nullptr) {
+#pragma unroll
+            for (int rt = 0; rt < WIDE_HT; ++rt) wide_store(act + tile * WIDE_TS, rt, col, hh, h[rt]);
+        }
+#pragma unroll 1
+        for (int l = 1; l < L; ++l) {
+            f32x16_t t[WIDE_HT];
+            wide_hidden<false>(image + g.offH + (l - 1) * g.strideH, h, t, lane, hh, sp);
+#pragma unroll
+            for (int rt = 0; rt < WIDE_HT; ++rt) h[rt] = t[rt];
+            if (act != nullptr) {
+#pragma unroll
+                for (int rt = 0; rt < WIDE_HT; ++rt) wide_store(act + ((int64_t)l * ntiles + tile) * WIDE_TS, rt, col, hh, h[rt]);
+            }
+        }
+        float ladj = 0.0f;
+        if constexpr (K != 0) {
+#pragma unroll 1
+            for (int i = 0; i < d; ++i) {
+                float v[32], gdummy[32];
+                wide_out_block<2, false>(image + g.off3 + i * g.stride3, h, v, lane, hh, sp.nin3[i]);
+                if (act != nullptr) wide_phi_store(PHI + ((int64_t)i * ntiles + tile) * 2048, lane, v);
+                float yi, li, gxd;
+                rqs_apply<K, 0>(v, xp[i], hh, yi, li, 0.0f, 0.0f, gdummy, gxd, bins_rt);
+                ladj += li;
+                if (valid && hh == 0) y[p * d + i] = yi;
+            }
+        } else {
+            float v[32];
+            wide_out_block<1, false>(image + g.off3, h, v, lane, hh, sp.ht);
+            if (act != nullptr) wide_phi_store(PHI + tile * 2048, lane, v);
+#pragma unroll 1
+            for (int i = 0; i < d; ++i) {
+                float shift, scale;
+                wide_affine_params(v, i, hh, shift, scale);
+                const float ls = soft_clip(scale, LOG_SLOPE_INV);
+                ladj += ls;
+                if (valid && hh == 0) y[p * d + i] = fmaf(xp[i], fast_exp(ls), shift);
+            }
+        }
+        if (valid && hh == 0) {
+            const float lp0 = init_logp ? base_log_prob(xp, d) : logp_in[p];
+            logp_out[p] = lp0 - ladj;
+        }
+    }
+}
+
+// =========================================================================================== backward
+template <int K, bool SAVED>      // SAVED: the forward handed its activations over (act): nothing is recomputed
 #ifndef MF_WIDE_BWD_WAVES
 #define MF_WIDE_BWD_WAVES 1            // one wave per SIMD: ~400 registers (the level-L-1 tile, dL/dh, the spline's adjoint state)
 #endif
 __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF_WIDE_BWD_WAVES) void wide_bwd_kernel(
     const float* __restrict__ image_arg, int d, int L, const float* __restrict__ x, int64_t n, const float* __restrict__ gy,
-    const float* __restrict__ glogp, float* __restrict__ gx, float* __restrict__ scratch, WideSp sp, int bins_rt) {
+    const float* __restrict__ glogp, float* __restrict__ gx, float* __restrict__ scratch, WideSp sp, int bins_rt,
+    const float* __restrict__ act) {
     const int nblk = (K != 0) ? d : 1;
     const WideLayout g = wide_layout(L, nblk);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
@@ -475,6 +523,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
     float* ACT = scratch;
     float* GPRE = ACT + (int64_t)L * ntiles * WIDE_TS;
     float* GPHI = GPRE + (int64_t)L * ntiles * WIDE_TS;
+    const float* const PHI = act + (int64_t)L * ntiles * WIDE_TS;      // (SAVED only)
     for (int64_t tile = (int64_t)blockIdx.x * (WIDE_BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (WIDE_BLOCK / 64)) {
         MF_NO_HOIST();                 // the image is loop invariant: keep its loads next to their MFMAs (flow_kernels.inc)
         uint64_t image_u = (uint64_t)image_arg;
@@ -487,29 +536,45 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
         float xb[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) xb[s] = (2 * s + hh < d) ? xp[2 * s + hh] : 0.0f;
-        // ---- recompute the trunk: every activation goes to the scratch, its sign bits stay in registers
         unsigned bits[WIDE_LMAX][WIDE_HT];
         f32x16_t h[WIDE_HT];
-        wide_input(image, g, d, xb, h, lane, hh, sp.ht);
+        if constexpr (SAVED) {
+            // ---- the hidden tiles come back from the hand-off buffer only to leave their sign bits (the ReLU masks): the
+            // contraction reads them from there itself, and the conditioner outputs are handed over as well
 #pragma unroll
-        for (int rt = 0; rt < WIDE_HT; ++rt) {
-            wide_store(ACT + tile * WIDE_TS, rt, col, hh, h[rt]);
-            bits[0][rt] = wide_bits(h[rt]);
-        }
-#pragma unroll
-        for (int l = 1; l < WIDE_LMAX; ++l) {
-            if (l < L) {
-                f32x16_t t[WIDE_HT];
-                wide_hidden<true>(image + g.offH + (l - 1) * g.strideH, h, t, lane, hh, sp);
+            for (int l = 0; l < WIDE_LMAX; ++l)
 #pragma unroll
                 for (int rt = 0; rt < WIDE_HT; ++rt) {
-                    h[rt] = t[rt];
-                    wide_store(ACT + ((int64_t)l * ntiles + tile) * WIDE_TS, rt, col, hh, h[rt]);
-                    bits[l][rt] = wide_bits(h[rt]);
+                    bits[l][rt] = 0;
+                    if (l < L && rt < sp.ht) {
+                        f32x16_t t;
+                        wide_load(act + ((int64_t)l * ntiles + tile) * WIDE_TS, rt, col, hh, t);
+                        bits[l][rt] = wide_bits(t);
+                    }
                 }
-            } else {
+        } else {
+            // ---- recompute the trunk: every activation goes to the scratch, its sign bits stay in registers
+            wide_input(image, g, d, xb, h, lane, hh, sp.ht);
 #pragma unroll
-                for (int rt = 0; rt < WIDE_HT; ++rt) bits[l][rt] = 0;
+            for (int rt = 0; rt < WIDE_HT; ++rt) {
+                wide_store(ACT + tile * WIDE_TS, rt, col, hh, h[rt]);
+                bits[0][rt] = wide_bits(h[rt]);
+            }
+#pragma unroll
+            for (int l = 1; l < WIDE_LMAX; ++l) {
+                if (l < L) {
+                    f32x16_t t[WIDE_HT];
+                    wide_hidden<true>(image + g.offH + (l - 1) * g.strideH, h, t, lane, hh, sp);
+#pragma unroll
+                    for (int rt = 0; rt < WIDE_HT; ++rt) {
+                        h[rt] = t[rt];
+                        wide_store(ACT + ((int64_t)l * ntiles + tile) * WIDE_TS, rt, col, hh, h[rt]);
+                        bits[l][rt] = wide_bits(h[rt]);
+                    }
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < WIDE_HT; ++rt) bits[l][rt] = 0;
+                }
             }
         }
         // ---- output blocks: transform forward + adjoint, accumulate dL/dh of the last hidden level
@@ -524,7 +589,8 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
                 float v[32], gv[32];
                 const gfp blk = image + g.off3 + i * g.stride3;
                 const int nin = sp.nin3[i];
-                wide_out_block<2, true>(blk, h, v, lane, hh, nin);
+                if constexpr (SAVED) wide_phi_load(PHI + ((int64_t)i * ntiles + tile) * 2048, lane, v);
+                else wide_out_block<2, true>(blk, h, v, lane, hh, nin);
                 const float gyi = valid ? gy[pc * d + i] : 0.0f;
                 float yi, li, gxd;
                 rqs_apply<K, 1>(v, xp[i], hh, yi, li, gyi, gl, gv, gxd, bins_rt);
@@ -562,7 +628,8 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
         } else {
             float v[32], gv[32];
             const gfp blk = image + g.off3;
-            wide_out_block<1, true>(blk, h, v, lane, hh, sp.ht);
+            if constexpr (SAVED) wide_phi_load(PHI + tile * 2048, lane, v);
+            else wide_out_block<1, true>(blk, h, v, lane, hh, sp.ht);
 #pragma unroll
             for (int m = 0; m < 32; ++m) gv[m] = 0.0f;
 #pragma unroll
@@ -664,7 +731,8 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
 // into JOBS of 64 x 64 (two column tiles of A times one or two column tiles of B); a wave owns one job, keeps the block in 64
 // accumulator registers over all the particle tiles it visits (grid-stride over blockIdx.x) and stores it into its slab row.
 struct WideJob {
-    int64_t a_base, b_base;     // float offsets into the scratch of column tile 0 of the job (b_base < 0: B = the layer input x)
+    int64_t a_base, b_base;     // float offsets of column tile 0 of the job: A into the scratch, B into the buffer that holds the
+                                // activations (the scratch, or the forward's hand-off buffer); b_base < 0: B = the layer input x
     int a_ts, b_ts;             // floats per particle tile
     int offW, strideW, offB;    // gradient-image position of C[0][0], its row stride, of the bias sums (-1: another job's)
     int nb;                     // column tiles of B (1 or 2)
@@ -685,6 +753,7 @@ constexpr int WIDE_OA_NB = 2;
 #endif
 
 __global__ __launch_bounds__(64 * WIDE_OA_WAVES) MF_WAVES_PER_SIMD(MF_WIDE_OA_OCC, MF_WIDE_OA_OCC) void wide_outer_accum_kernel(const float* __restrict__ scratch,
+                                                                              const float* __restrict__ actbuf,
                                                                               const float* __restrict__ x, int64_t n, int d,
                                                                               float* __restrict__ gslab, int64_t gtotal,
                                                                               int accumulate, WideJobs jobs) {
@@ -703,7 +772,7 @@ __global__ __launch_bounds__(64 * WIDE_OA_WAVES) MF_WAVES_PER_SIMD(MF_WIDE_OA_OC
         for (int b = 0; b < WIDE_OA_NB; ++b) acc[a][b] = wide_zero();
     float bsum0 = 0.0f, bsum1 = 0.0f;
     const float* A = scratch + jb.a_base;
-    const float* B = scratch + (from_x ? 0 : jb.b_base);
+    const float* B = actbuf + (from_x ? 0 : jb.b_base);
     // lane (col, hh): column 32 t + col, particles 16 hh + s (s = 0..15): k-step s pairs particles (s, 16 + s)
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 #pragma unroll 1
@@ -943,18 +1012,39 @@ extern "C" int mf_flow_wide_limits(int* max_features, int* max_hidden, int* max_
 extern "C" int64_t mf_flow_wide_image_floats(int hidden_layers, int nblk) { return wide_layout(hidden_layers, nblk).total; }
 extern "C" int64_t mf_flow_wide_grad_floats(int hidden_layers, int nblk) { return wide_grad_layout(hidden_layers, nblk).total; }
 
-extern "C" int mf_flow_wide_layer_fwd(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
-                                       const float* x, int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp,
-                                       void* stream) {
+static int wide_layer_fwd_impl(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
+                               const float* x, int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp, float* act,
+                               void* stream) {
     if (wide_check(d, hidden, hidden_layers, bins, n)) return 1;
     if (n == 0) return 0;
     const WideSp sp = make_wide_sp(d, order, hidden, bins ? d : 1);
     ProfScope prof(PK_FLOW_FWD, stream);
 #define CALL(KK) MF_LAUNCH((wide_fwd_kernel<KK>), wide_grid(n), WIDE_BLOCK, 0, stream, image, d, hidden_layers, x, n, y, logp_in, \
-                           logp_out, init_logp, sp, bins)
+                           logp_out, init_logp, sp, bins, act)
     MF_WIDE_DISPATCH(bins, CALL);
 #undef CALL
     return check_launch("mf_flow_wide_layer_fwd");
+}
+
+extern "C" int mf_flow_wide_layer_fwd(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
+                                       const float* x, int64_t n, float* y, const float* logp_in, float* logp_out, int init_logp,
+                                       void* stream) {
+    return wide_layer_fwd_impl(image, d, hidden, hidden_layers, bins, order, x, n, y, logp_in, logp_out, init_logp, nullptr, stream);
+}
+
+// ---- activation hand-off (training forward -> backward through HBM; wide_act_floats) -------------------------------------------
+extern "C" int64_t mf_flow_wide_act_floats(int64_t n, int d, int hidden_layers, int bins) {
+    if (n <= 0 || d < 1 || hidden_layers < 1) return 0;
+    return wide_act_floats((n + 31) / 32, hidden_layers, bins ? d : 1);
+}
+
+extern "C" int mf_flow_wide_layer_fwd_save(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
+                                            const float* x, int64_t n, float* y, const float* logp_in, float* logp_out,
+                                            int init_logp, float* act, int64_t act_floats, void* stream) {
+    if (n > 0 && (act == nullptr || act_floats < mf_flow_wide_act_floats(n, d, hidden_layers, bins)))
+        return fail("act buffer too small: %lld floats, need %lld (mf_flow_wide_act_floats)", (long long)act_floats,
+                    (long long)mf_flow_wide_act_floats(n, d, hidden_layers, bins));
+    return wide_layer_fwd_impl(image, d, hidden, hidden_layers, bins, order, x, n, y, logp_in, logp_out, init_logp, act, stream);
 }
 
 extern "C" int64_t mf_flow_wide_bwd_scratch_floats(int64_t n, int d, int hidden_layers, int bins) {
@@ -970,9 +1060,9 @@ extern "C" int mf_flow_wide_bwd_slab_rows(int64_t n) {
     return (int)(G < 1 ? 1 : G);
 }
 
-extern "C" int mf_flow_wide_layer_bwd(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
-                                       const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gslab,
-                                       int slab_rows, int accumulate, float* scratch, int64_t scratch_floats, void* stream) {
+static int wide_layer_bwd_impl(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
+                               const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gslab,
+                               int slab_rows, int accumulate, float* scratch, int64_t scratch_floats, const float* act, void* stream) {
     if (wide_check(d, hidden, hidden_layers, bins, n)) return 1;
     if (n == 0) return 0;
     if (scratch_floats < mf_flow_wide_bwd_scratch_floats(n, d, hidden_layers, bins)) return fail("scratch too small");
@@ -982,18 +1072,41 @@ extern "C" int mf_flow_wide_layer_bwd(const float* image, int d, int hidden, int
     const WideSp sp = make_wide_sp(d, order, hidden, nblk);
     {
         ProfScope prof(PK_FLOW_BWD, stream);
-#define CALL(KK) MF_LAUNCH((wide_bwd_kernel<KK>), wide_grid(n), WIDE_BLOCK, 0, stream, image, d, hidden_layers, x, n, gy, glogp, gx, \
-                           scratch, sp, bins)
+#define CALL(KK)                                                                                                                  \
+    if (act != nullptr)                                                                                                           \
+        MF_LAUNCH((wide_bwd_kernel<KK, true>), wide_grid(n), WIDE_BLOCK, 0, stream, image, d, hidden_layers, x, n, gy, glogp, gx,  \
+                  scratch, sp, bins, act);                                                                                        \
+    else                                                                                                                          \
+        MF_LAUNCH((wide_bwd_kernel<KK, false>), wide_grid(n), WIDE_BLOCK, 0, stream, image, d, hidden_layers, x, n, gy, glogp, gx, \
+                  scratch, sp, bins, act)
         MF_WIDE_DISPATCH(bins, CALL);
 #undef CALL
     }
     if (check_launch("mf_flow_wide_layer_bwd")) return 1;
     const WideJobs jobs = make_wide_jobs(n, hidden_layers, nblk, sp);
     ProfScope prof(PK_OUTER_ACCUM, stream);
+    // the B operands (hidden activations): from the forward's hand-off buffer when there is one — same [L][ntiles][HT*1024] layout as
+    // the ACT part of the scratch, which the backward then leaves unwritten
     MF_LAUNCH(wide_outer_accum_kernel, dim3((unsigned)slab_rows, (unsigned)((jobs.count + WIDE_OA_WAVES - 1) / WIDE_OA_WAVES)),
-              64 * WIDE_OA_WAVES, 0, stream, scratch, x, n, d, gslab, (int64_t)wide_grad_layout(hidden_layers, nblk).total, accumulate,
-              jobs);
+              64 * WIDE_OA_WAVES, 0, stream, scratch, act != nullptr ? act : scratch, x, n, d, gslab,
+              (int64_t)wide_grad_layout(hidden_layers, nblk).total, accumulate, jobs);
     return check_launch("mf_flow_wide_layer_bwd(outer_accum)");
+}
+
+extern "C" int mf_flow_wide_layer_bwd(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
+                                       const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gslab,
+                                       int slab_rows, int accumulate, float* scratch, int64_t scratch_floats, void* stream) {
+    return wide_layer_bwd_impl(image, d, hidden, hidden_layers, bins, order, x, n, gy, glogp, gx, gslab, slab_rows, accumulate, scratch,
+                               scratch_floats, nullptr, stream);
+}
+
+extern "C" int mf_flow_wide_layer_bwd_saved(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,
+                                             const float* x, int64_t n, const float* gy, const float* glogp, float* gx, float* gslab,
+                                             int slab_rows, int accumulate, float* scratch, int64_t scratch_floats, const float* act,
+                                             int64_t act_floats, void* stream) {
+    if (n > 0 && (act == nullptr || act_floats < mf_flow_wide_act_floats(n, d, hidden_layers, bins))) return fail("act buffer too small");
+    return wide_layer_bwd_impl(image, d, hidden, hidden_layers, bins, order, x, n, gy, glogp, gx, gslab, slab_rows, accumulate, scratch,
+                               scratch_floats, act, stream);
 }
 
 extern "C" int mf_flow_wide_layer_inv(const float* image, int d, int hidden, int hidden_layers, int bins, const int32_t* order,

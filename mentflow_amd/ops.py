@@ -59,9 +59,19 @@ class FlowSpec:
         self._act_supported: Optional[int] = None
 
     def resolve_act_level(self, n: int, device: torch.device) -> int:
-        if self.kind != "rqs" or not self.sparse or self.wide or n <= 0:
+        if n <= 0:
             return 0
         lib = _lib.get_lib()
+        if self.wide:
+            # one level: hidden tiles + conditioner outputs (mf_flow_wide_layer_fwd_save), if T such buffers fit the budget
+            want = 1 if self.act_level is None else min(int(self.act_level), 1)
+            budget = self.act_budget_bytes
+            if budget is None:
+                budget = int(0.6 * torch.cuda.get_device_properties(device).total_memory) if device.type == "cuda" else 1 << 62
+            bins = self.bins if self.kind == "rqs" else 0
+            return want if want > 0 and 4 * self.T * lib.mf_flow_wide_act_floats(n, self.d, self.L, bins) <= budget else 0
+        if self.kind != "rqs" or not self.sparse:
+            return 0
         supported = min(lib.mf_flow_rqs_act_level(self.d, self.L, self.bins, o) for o in self.orders)
         want = supported if self.act_level is None else min(int(self.act_level), supported)
         budget = self.act_budget_bytes
@@ -77,7 +87,10 @@ def _layer_fwd(spec: FlowSpec, t: int, image: torch.Tensor, x: torch.Tensor, y: 
                act_level: int = 0) -> None:
     n = x.shape[0]
     order = spec.orders[t] if spec.sparse else None
-    if spec.wide:
+    if spec.wide and act_level > 0:
+        call("mf_flow_wide_layer_fwd_save", ptr(image), spec.d, spec.hidden, spec.L, spec.bins if spec.kind == "rqs" else 0, order,
+             ptr(x), n, ptr(y), ptr(logp_in), ptr(logp_out), int(init), ptr(act), act.numel(), stream_ptr(x))
+    elif spec.wide:
         call("mf_flow_wide_layer_fwd", ptr(image), spec.d, spec.hidden, spec.L, spec.bins if spec.kind == "rqs" else 0, order,
              ptr(x), n, ptr(y), ptr(logp_in), ptr(logp_out), int(init), stream_ptr(x))
     elif act_level > 0:
@@ -96,7 +109,11 @@ def _layer_bwd(spec: FlowSpec, t: int, image, x, gy, glogp, gx, gslab, accumulat
     n = x.shape[0]
     order = spec.orders[t] if spec.sparse else None
     rows = gslab.shape[0]
-    if spec.wide:
+    if spec.wide and act_level > 0:
+        call("mf_flow_wide_layer_bwd_saved", ptr(image), spec.d, spec.hidden, spec.L, spec.bins if spec.kind == "rqs" else 0, order,
+             ptr(x), n, ptr(gy), ptr(glogp), ptr(gx), ptr(gslab), rows, int(accumulate), ptr(scratch), scratch.numel(), ptr(act),
+             act.numel(), stream_ptr(x))
+    elif spec.wide:
         call("mf_flow_wide_layer_bwd", ptr(image), spec.d, spec.hidden, spec.L, spec.bins if spec.kind == "rqs" else 0, order,
              ptr(x), n, ptr(gy), ptr(glogp), ptr(gx), ptr(gslab), rows, int(accumulate), ptr(scratch), scratch.numel(),
              stream_ptr(x))
@@ -111,7 +128,7 @@ def _layer_bwd(spec: FlowSpec, t: int, image, x, gy, glogp, gx, gslab, accumulat
              ptr(gslab), rows, int(accumulate), ptr(scratch), scratch.numel(), stream_ptr(x))
 
 
-def _bwd_plan(spec: FlowSpec, n: int):
+def _bwd_plan(spec: FlowSpec, n: int, whole: bool = False):
     """(chunk, scratch_floats, slab_rows) of a backward pass over n particles: the fused kernels need no scratch and
     take the whole batch in one launch per layer; the two-kernel path is chunked to bound its hand-off scratch.  Every
     chunk of a pass must write the same number of slab rows (each workgroup accumulates into its own row), so a ragged
@@ -141,7 +158,8 @@ def _bwd_plan(spec: FlowSpec, n: int):
         def rows(m):
             return lib.mf_flow_affine_bwd_slab_rows(m)
 
-    chunk = n if need(n) == 0 else min(n, spec.bwd_chunk)
+    # whole: one chunk whatever the scratch costs (the wide family's saved activations cover the batch as one tile sequence)
+    chunk = n if (need(n) == 0 or whole) else min(n, spec.bwd_chunk)
     return chunk, need(chunk), rows
 
 
@@ -176,7 +194,10 @@ class FlowSampleFn(torch.autograd.Function):
         logp = torch.empty(n, dtype=_F32, device=z.device)
         level = spec.resolve_act_level(n, z.device)
         act = None
-        if level > 0:
+        if level > 0 and spec.wide:
+            act = torch.empty(spec.T, _lib.get_lib().mf_flow_wide_act_floats(n, spec.d, spec.L, spec.bins if spec.kind == "rqs" else 0),
+                              dtype=_F32, device=z.device)
+        elif level > 0:
             act = torch.empty(spec.T, _lib.get_lib().mf_flow_rqs_act_floats(n, spec.d, spec.L, spec.bins, level), dtype=_F32, device=z.device)
         xs = [z]
         for t in range(spec.T):
@@ -200,8 +221,8 @@ class FlowSampleFn(torch.autograd.Function):
         dev = images.device
         gx = torch.zeros(n, spec.d, dtype=_F32, device=dev) if gx is None else _f32c(gx)
         glogp = torch.zeros(n, dtype=_F32, device=dev) if glogp is None else _f32c(glogp)
-        chunk, scratch_floats, rows_of = _bwd_plan(spec, n)
         level = ctx.act_level
+        chunk, scratch_floats, rows_of = _bwd_plan(spec, n, whole=spec.wide and level > 0)
         act = act if level > 0 else None
         if level > 0 and chunk != n:
             raise RuntimeError("the backward variant changed between forward and backward: the saved activations belong to the "

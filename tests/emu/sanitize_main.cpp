@@ -135,6 +135,29 @@ static void flow_wide(int d, int hidden, int L, int K, int64_t n) {
     all_finite(gx, "wide gx");
     CK(mf_flow_wide_layer_inv(image.data(), d, hidden, L, K, order.data(), y.data(), n, x2.data(), nullptr));
     all_finite(x2, "wide inverse");
+    // activation hand-off: exactly-sized buffer, every float of it written by the forward; the backward that loads it must reproduce
+    // dL/dx and the slab of the recomputing backward bit for bit
+    {
+        const int64_t af = mf_flow_wide_act_floats(n, d, L, K);
+        std::vector<float> act((size_t)af, NAN), y2(n * d), logp2(n), gx1(n * d), gx2(n * d), slab1((size_t)rows * G, NAN),
+            slab2((size_t)rows * G, NAN), scratch2((size_t)sf, NAN);
+        CK(mf_flow_wide_layer_fwd_save(image.data(), d, hidden, L, K, order.data(), x.data(), n, y2.data(), nullptr, logp2.data(), 1,
+                                       act.data(), af, nullptr));
+        all_finite(act, "wide act");
+        CK(mf_flow_wide_layer_bwd(image.data(), d, hidden, L, K, order.data(), x.data(), n, gy.data(), gl.data(), gx1.data(), slab1.data(),
+                                  rows, 0, scratch.data(), sf, nullptr));
+        CK(mf_flow_wide_layer_bwd_saved(image.data(), d, hidden, L, K, order.data(), x.data(), n, gy.data(), gl.data(), gx2.data(),
+                                        slab2.data(), rows, 0, scratch2.data(), sf, act.data(), af, nullptr));
+        if (memcmp(gx1.data(), gx2.data(), gx1.size() * sizeof(float)) != 0) {
+            fprintf(stderr, "wide hand-off: dL/dx differs from the recomputing backward (d=%d hidden=%d L=%d bins=%d)\n", d, hidden, L, K);
+            exit(4);
+        }
+        for (size_t i = 0; i < slab1.size(); ++i)            // positions no job writes stay NaN in both
+            if (memcmp(&slab1[i], &slab2[i], sizeof(float)) != 0) {
+                fprintf(stderr, "wide hand-off: slab position %zu differs (d=%d hidden=%d L=%d bins=%d)\n", i, d, hidden, L, K);
+                exit(4);
+            }
+    }
     printf("  wide d=%d hidden=%d L=%d bins=%d n=%ld: image %ld, gradient image %ld floats, slab rows %d, scratch %ld floats\n", d, hidden,
            L, K, (long)n, (long)F, (long)G, rows, (long)sf);
 }

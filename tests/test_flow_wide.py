@@ -78,18 +78,28 @@ def test_wide_dz_and_chunked_backward(backend):
     z = (torch.randn(n, 5) * 1.2)
     wx, wl = torch.randn(n, 5), torch.randn(n)
 
-    def run(chunk):
+    def run(chunk, level):
         gen.zero_grad(set_to_none=True)
         gen.spec().bwd_chunk = chunk
+        gen.spec().act_level = level                        # 0: the backward recomputes the conditioner (and may be chunked)
         zz = z.to(backend).clone().requires_grad_(True)
         x, lp = gen.sample_and_log_prob(n, z=zz)
         ((x * wx.to(backend)).sum() + (lp * wl.to(backend)).sum()).backward()
         return zz.grad.cpu(), torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).cpu()
 
-    gz1, gp1 = run(1 << 20)
-    gz2, gp2 = run(96)
+    gz1, gp1 = run(1 << 20, 0)
+    gz2, gp2 = run(96, 0)
     assert torch.equal(gz1, gz2)
     assert (gp1 - gp2).abs().max() <= 2e-6 * gp1.abs().max()
+    # activation hand-off (the default): the forward's hidden tiles and conditioner outputs instead of recomputed ones — the same
+    # values through the same arithmetic (bitwise on the emulator; on the GPU the two instantiations contract fp32 differently)
+    assert gen.spec().resolve_act_level(n, backend) == 0
+    gz3, gp3 = run(1 << 20, None)
+    assert gen.spec().resolve_act_level(n, backend) == 1
+    if backend.type == "cpu":
+        assert torch.equal(gz1, gz3) and torch.equal(gp1, gp3)
+    else:
+        assert (gz1 - gz3).abs().max() <= 2e-6 * gz1.abs().max() and (gp1 - gp3).abs().max() <= 2e-6 * gp1.abs().max()
     s64 = flow_spec_from_generator(gen, torch.float64)
     zo = z.double().requires_grad_(True)
     xo, lo = of.sample_and_log_prob(zo, s64)
