@@ -402,19 +402,15 @@ __device__ __forceinline__ void wide_mask(f32x16_t& gh, unsigned bits) {
     }
 }
 
-__device__ __forceinline__ void wide_load(const float* __restrict__ src, int rt, int col, int hh, f32x16_t& a) {
-    const float* base = src + (32 * rt + 16 * hh) * 32 + col;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = base[r * 32];
-}
-
 // Activation hand-off of the wide family (forward -> backward through HBM, as §4.2 of DESIGN.md does for the 64-wide kernels): a
 // training forward stores, per layer,  ACTH[L][ntiles][HT*1024]  — every hidden level in the SCRATCH-TILE layout, so that the
 // contraction kernel reads its B operands straight from it and the backward neither recomputes nor re-writes them — and
 // PHI[nblk][ntiles][2048]  — the conditioner outputs of every output block in the register layout of the wave (float4[8][lane]).
 // 3 KB per particle and layer at 128 units, d = 6, three hidden layers.
+// ... and  BITS[L][ntiles][HT][64]  — the sign bits of every hidden tile (bit r of lane l's word = register r is positive): the
+// backward needs the hidden values themselves only as ReLU masks, 12 words per lane instead of 192 loads.
 __host__ __device__ inline int64_t wide_act_floats(int64_t ntiles, int L, int nblk) {
-    return ntiles * ((int64_t)L * WIDE_TS + (int64_t)nblk * 2048);
+    return ntiles * ((int64_t)L * WIDE_TS + (int64_t)nblk * 2048 + (int64_t)L * WIDE_HT * 64);
 }
 __device__ __forceinline__ void wide_phi_store(float* __restrict__ blk, int lane, const float (&v)[32]) {
     act_f4* q = reinterpret_cast<act_f4*>(blk) + lane;
@@ -447,6 +443,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(2, 2) void wide_fwd_k
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
     const int64_t ntiles = (n + 31) / 32;
     float* const PHI = act + (int64_t)L * ntiles * WIDE_TS;
+    unsigned* const BITS = reinterpret_cast<unsigned*>(PHI + (int64_t)nblk * ntiles * 2048);
     for (int64_t tile = (int64_t)blockIdx.x * (WIDE_BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (WIDE_BLOCK / 64)) {
         MF_NO_HOIST();                 // the image is loop invariant: keep its loads next to their MFMAs (flow_kernels.inc)
         uint64_t image_u = (uint64_t)image_arg;
@@ -462,7 +459,10 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(2, 2) void wide_fwd_k
         wide_input(image, g, d, xb, h, lane, hh, sp.ht);
         if (act != nullptr) {
 #pragma unroll
-            for (int rt = 0; rt < WIDE_HT; ++rt) wide_store(act + tile * WIDE_TS, rt, col, hh, h[rt]);
+            for (int rt = 0; rt < WIDE_HT; ++rt) {
+                wide_store(act + tile * WIDE_TS, rt, col, hh, h[rt]);
+                BITS[(tile * WIDE_HT + rt) * 64 + lane] = wide_bits(h[rt]);
+            }
         }
 #pragma unroll 1
         for (int l = 1; l < L; ++l) {
@@ -472,7 +472,10 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(2, 2) void wide_fwd_k
             for (int rt = 0; rt < WIDE_HT; ++rt) h[rt] = t[rt];
             if (act != nullptr) {
 #pragma unroll
-                for (int rt = 0; rt < WIDE_HT; ++rt) wide_store(act + ((int64_t)l * ntiles + tile) * WIDE_TS, rt, col, hh, h[rt]);
+                for (int rt = 0; rt < WIDE_HT; ++rt) {
+                    wide_store(act + ((int64_t)l * ntiles + tile) * WIDE_TS, rt, col, hh, h[rt]);
+                    BITS[(((int64_t)l * ntiles + tile) * WIDE_HT + rt) * 64 + lane] = wide_bits(h[rt]);
+                }
             }
         }
         float ladj = 0.0f;
@@ -524,6 +527,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
     float* GPRE = ACT + (int64_t)L * ntiles * WIDE_TS;
     float* GPHI = GPRE + (int64_t)L * ntiles * WIDE_TS;
     const float* const PHI = act + (int64_t)L * ntiles * WIDE_TS;      // (SAVED only)
+    const unsigned* const BITS = reinterpret_cast<const unsigned*>(PHI + (int64_t)nblk * ntiles * 2048);
     for (int64_t tile = (int64_t)blockIdx.x * (WIDE_BLOCK / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (WIDE_BLOCK / 64)) {
         MF_NO_HOIST();                 // the image is loop invariant: keep its loads next to their MFMAs (flow_kernels.inc)
         uint64_t image_u = (uint64_t)image_arg;
@@ -539,19 +543,13 @@ __global__ __launch_bounds__(WIDE_BLOCK) MF_WAVES_PER_SIMD(MF_WIDE_BWD_WAVES, MF
         unsigned bits[WIDE_LMAX][WIDE_HT];
         f32x16_t h[WIDE_HT];
         if constexpr (SAVED) {
-            // ---- the hidden tiles come back from the hand-off buffer only to leave their sign bits (the ReLU masks): the
-            // contraction reads them from there itself, and the conditioner outputs are handed over as well
+            // ---- of the hidden tiles the backward itself only needs the sign bits (the ReLU masks): the contraction reads the
+            // values from the hand-off buffer on its own, and the conditioner outputs are handed over as well
 #pragma unroll
             for (int l = 0; l < WIDE_LMAX; ++l)
 #pragma unroll
-                for (int rt = 0; rt < WIDE_HT; ++rt) {
-                    bits[l][rt] = 0;
-                    if (l < L && rt < sp.ht) {
-                        f32x16_t t;
-                        wide_load(act + ((int64_t)l * ntiles + tile) * WIDE_TS, rt, col, hh, t);
-                        bits[l][rt] = wide_bits(t);
-                    }
-                }
+                for (int rt = 0; rt < WIDE_HT; ++rt)
+                    bits[l][rt] = (l < L) ? BITS[(((int64_t)l * ntiles + tile) * WIDE_HT + rt) * 64 + lane] : 0u;
         } else {
             // ---- recompute the trunk: every activation goes to the scratch, its sign bits stay in registers
             wide_input(image, g, d, xb, h, lane, hh, sp.ht);
