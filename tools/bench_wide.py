@@ -6,8 +6,8 @@ shape, one MENTFlow.loss() + backward + AdamW step per iteration — the step be
 
 Prints one JSON line: ms per step, particle-samples/s, the per-kernel split from the library's HIP-event profile and the flow
 kernels' dense-equivalent fp32 FLOP rate: F = 2 (d h + (L-1) h^2 + h q d) per particle and layer for the forward; the per-tile
-backward kernel recomputes the conditioner and runs the transposed chains (2 F), the contraction kernel forms the parameter
-gradients (F).  Dense-equivalent: the kernels skip the all-zero 32 x 32 blocks of the autoregressive masks."""
+backward kernel runs the transposed chains (F; 2 F when it also recomputes the conditioner: MENTFLOW_ACT_LEVEL=0), the contraction
+kernel forms the parameter gradients (F).  Dense-equivalent: the kernels skip the all-zero 32 x 32 blocks of the autoregressive masks."""
 import argparse
 import json
 import os
@@ -68,7 +68,8 @@ def main():
     _lib.prof_enable(False)
     d, h, Lh, q, T = args.ndim, args.hidden_units, args.hidden_layers, 59, 5
     flops = 2 * (d * h + (Lh - 1) * h * h + h * q * d)
-    out = {"wide": bool(model.generator.wide), "ndim": d, "hidden_units": h, "hidden_layers": Lh, "particles": n,
+    level = model.generator.spec().resolve_act_level(n, dev)
+    out = {"wide": bool(model.generator.wide), "activation_handoff": int(level), "ndim": d, "hidden_units": h, "hidden_layers": Lh, "particles": n,
            "ms_per_step": 1e3 * el / args.steps, "particle_samples_per_s": n * args.steps / el, "final_loss": float(L.detach()),
            "kernels_ms_per_step": {k: ms / args.steps for k, (ms, cnt) in prof.items() if cnt},
            "launches_per_step": {k: cnt / args.steps for k, (ms, cnt) in prof.items() if cnt}}
@@ -76,7 +77,7 @@ def main():
     if "flow_layer_fwd" in ks:
         out["fwd_dense_tflops"] = flops * n * T / (ks["flow_layer_fwd"] * 1e-3) / 1e12
     if "flow_layer_bwd" in ks:
-        out["bwd_dense_tflops"] = 2 * flops * n * T / (ks["flow_layer_bwd"] * 1e-3) / 1e12
+        out["bwd_dense_tflops"] = (1 if (level > 0 and model.generator.wide) else 2) * flops * n * T / (ks["flow_layer_bwd"] * 1e-3) / 1e12
     if "outer_accum" in ks:
         out["outer_accum_dense_tflops"] = flops * n * T / (ks["outer_accum"] * 1e-3) / 1e12
     print(json.dumps(out))
