@@ -13,9 +13,11 @@
 //   * mask sparsity at TILE granularity: hidden units are placed sorted by dependency class (packing.py), so the
 //     autoregressive masks are block-triangular over 32-unit tiles; wave-uniform tile counts skip the all-zero blocks
 //     (13 of 16 hidden blocks and 14 of 24 last-layer blocks remain at 128 units, d = 6).
-//   * the backward is the two-kernel form: a per-tile kernel recomputes the conditioner, runs the adjoint, produces dL/dx and
-//     writes activations and pre-activation gradients to an HBM scratch; wide_outer_accum_kernel contracts them over particles
-//     into slab rows of a NATURAL-layout gradient image (mf_flow_wide_grad_floats), summed by mf_flow_grad_reduce.
+//   * the backward is the two-kernel form: a per-tile kernel runs the adjoint, produces dL/dx and writes the pre-activation
+//     gradients to an HBM scratch; wide_outer_accum_kernel contracts them with the activations over particles into slab rows of a
+//     NATURAL-layout gradient image (mf_flow_wide_grad_floats), summed by mf_flow_grad_reduce.  The activations come from the
+//     training forward (hand-off through HBM: hidden tiles in the scratch layout, conditioner outputs, ReLU sign bits —
+//     mf_flow_wide_layer_fwd_save / _bwd_saved) or, without it, are recomputed and written by the per-tile kernel.
 //   * hidden_layers is a run-time argument (1 .. 4).
 #include "flow_launch.h"
 #include <stdlib.h>
