@@ -383,7 +383,14 @@ __device__ __forceinline__ void wide_affine_params(const float (&v)[32], int i, 
 __device__ __forceinline__ void wide_store(float* __restrict__ dst, int rt, int col, int hh, const f32x16_t& a) {
     float* base = dst + (32 * rt + 16 * hh) * 32 + col;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) base[r * 32] = a[r];
+    for (int r = 0; r < 16; ++r) {
+        const float t = a[r];
+#ifdef MF_WIDE_PLAIN_STORES
+        base[r * 32] = t;
+#else
+        MF_ACT_ST(base + r * 32, t);           // written once, read once by another kernel: non-temporal (26.6 vs 26.9 ms per step)
+#endif
+    }
 }
 
 // sign bits of a post-ReLU tile (bit r = register r is positive) and their use as the ReLU mask of a gradient tile
