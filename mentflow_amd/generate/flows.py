@@ -16,6 +16,7 @@ reference's 25 000-particle batch that host / launch overhead is a third of the 
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -112,7 +113,7 @@ class AutoregressiveFlow(GenerativeModel):
         # weights in LDS (narrower layers ride zero-padded in the 64-wide image).  Beyond (hidden_units 65 .. 128 or 8 .. 16
         # features; mentflow/generate/build.py:36-38 takes both from the config): the wide family, weights in global memory as MFMA
         # fragment blocks (mentflow_amd/csrc/flow_wide.hip) — the 128-wide last layer alone is 198 KB at d = 6, against 160 KB of LDS.
-        self.wide = max(widths) > packing.HID or features > 7
+        self.wide = max(widths) > packing.HID or features > 7 or os.environ.get("MENTFLOW_FORCE_WIDE", "") == "1"   # (env: A/B runs)
         self.features, self.kind, self.bins = int(features), kind, int(bins)
         self.hidden_features = tuple(int(h) for h in hidden_features)
         self.total = 3 * self.bins - 1 if kind == "rqs" else 2
